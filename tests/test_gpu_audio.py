@@ -1,0 +1,126 @@
+"""GPU parity of the vocoder path (spec -> magnitudes, STFT, ISTFT, Griffin-Lim, de-emphasis)
+against the CPU oracle.  Bars: STFT/ISTFT max-abs 1e-4 relative to signal scale, Griffin-Lim
+waveform SNR >= 40 dB against the oracle started from the same initial phase."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _snr_db(ref, got):
+    ref = np.asarray(ref, dtype=np.float64)
+    err = ref - np.asarray(got, dtype=np.float64)
+    return 10 * np.log10((ref ** 2).sum() / max((err ** 2).sum(), 1e-300))
+
+
+def _aps(v1=False, iters=60):
+    from oracle import audio_oracle as ao
+    from tts_amd.audio import AudioProcessor
+    cfg = dict(ao.T1_AUDIO if v1 else ao.T2_AUDIO, griffin_lim_iters=iters)
+    orc = ao.AudioOracle(**cfg)
+    kw = {k: v for k, v in cfg.items() if k not in ("pad_mode", "win_from_hop")}
+    ap = AudioProcessor(tacotron_v1=v1, verbose=False, **kw)
+    return orc, ap
+
+
+def _smooth_mel(seed, n_mels, F, scale=1.5):
+    from tts_amd import synthetic
+    m = synthetic.normal(seed, "mel", (n_mels, F + 4), 0.0, scale)
+    return np.stack([np.convolve(r, np.ones(5) / 5, mode="valid") for r in m]).astype(np.float32)
+
+
+@pytest.mark.parametrize("v1", [False, True])
+def test_stft_istft_match_oracle(v1):
+    orc, ap = _aps(v1)
+    assert (ap.n_fft, ap.hop_length, ap.win_length) == (orc.n_fft, orc.hop_length, orc.win_length)
+    rng = np.random.default_rng(3)
+    for F in (2, 5, 9, 64):
+        y = (rng.standard_normal(ap.hop_length * (F - 1)) * 0.3).astype(np.float32)
+        X_ref = orc._stft(y)
+        X = ap._stft(y)
+        assert X.shape == X_ref.shape == (1025, F)
+        assert np.abs(X - X_ref).max() < 1e-4 * max(1.0, np.abs(X_ref).max())
+        y_ref = orc._istft(X_ref.astype(np.complex128))
+        y_got = ap._istft(X_ref)
+        assert y_got.shape == y_ref.shape
+        assert np.abs(y_got - y_ref).max() < 1e-5
+
+
+def test_spec_to_mag_matches_oracle():
+    orc, ap = _aps(False)
+    mel = _smooth_mel(11, 80, 57, 2.5)
+    ref = orc.spec_from_mel(mel, ap._build_mel_basis().__class__ and np.linalg.pinv(ap._build_mel_basis()))
+    got = ap.spec_to_mag(torch.from_numpy(mel.T.copy()).cuda().unsqueeze(0))[0].cpu().numpy().T
+    rel = np.abs(got - ref) / np.maximum(np.abs(ref), 1e-6)
+    # fp32 sums of 80 terms with cancellation: compare against the magnitude scale of each frame
+    assert (np.abs(got - ref) / (np.abs(ref).max(axis=0, keepdims=True) + 1e-12)).max() < 1e-4, rel.max()
+    orc1, ap1 = _aps(True)
+    lin = np.clip(_smooth_mel(12, 1025, 9, 0.4) + 0.5, -0.2, 1.2)
+    ref = orc1.spec_from_linear(lin)
+    got = ap1.spec_to_mag(torch.from_numpy(lin.T.copy()).cuda().unsqueeze(0), mel=False)[0].cpu().numpy().T
+    assert (np.abs(got - ref) / np.maximum(np.abs(ref), 1e-9)).max() < 1e-4
+
+
+def test_mel_basis_host_code_matches_oracle():
+    from oracle import audio_oracle as ao
+    orc, ap = _aps(False)
+    np.testing.assert_array_equal(ap._build_mel_basis(), orc._build_mel_basis())
+
+
+@pytest.mark.parametrize("v1,F", [(False, 40), (False, 173), (True, 61)])
+def test_griffin_lim_snr(v1, F):
+    from tts_amd import synthetic
+    orc, ap = _aps(v1, iters=60)
+    if v1:
+        spec = np.clip(_smooth_mel(21, 1025, F, 0.25) + 0.45, 0.0, 1.0)
+        S = orc.spec_from_linear(spec)
+    else:
+        mel = _smooth_mel(22, 80, F, 1.5)
+        S = orc.spec_from_mel(mel)
+    S = S.astype(np.float32)
+    ph = synthetic.gl_init_phase(9, 1025, F)
+    y_ref = orc._griffin_lim(S, ph)
+    y = ap._griffin_lim(S, init_phase=ph)
+    assert y.shape == y_ref.shape == (ap.hop_length * (F - 1),)
+    snr = _snr_db(y_ref, y)
+    assert snr >= 40.0, "Griffin-Lim SNR %.1f dB" % snr
+
+
+def test_inv_mel_spectrogram_end_to_end_and_ragged_batch():
+    from tts_amd import synthetic
+    orc, ap = _aps(False, iters=30)
+    Fs = [33, 50, 12]
+    mels = [_smooth_mel(40 + i, 80, F, 1.5) for i, F in enumerate(Fs)]
+    phs = [synthetic.gl_init_phase(50 + i, 1025, F) for i, F in enumerate(Fs)]
+    refs = [orc.inv_mel_spectrogram(m, p, np.linalg.pinv(ap._build_mel_basis())) for m, p in zip(mels, phs)]
+    # reference-shaped call, one utterance
+    y0 = ap.inv_mel_spectrogram(mels[0], init_phase=phs[0])
+    assert y0.dtype == np.float64 and y0.shape == refs[0].shape
+    assert _snr_db(refs[0], y0) >= 40.0
+    # ragged batch through the batched device API
+    Fm = max(Fs)
+    spec = torch.zeros(3, Fm, 80)
+    ph = torch.zeros(3, Fm, 1025)
+    for b, F in enumerate(Fs):
+        spec[b, :F] = torch.from_numpy(mels[b].T.copy())
+        ph[b, :F] = torch.from_numpy(phs[b].T.astype(np.float32).copy())
+    mag = ap.spec_to_mag(spec.cuda())
+    wav = ap.griffin_lim_batch(mag, ph.cuda(), torch.tensor(Fs)).cpu().numpy()
+    for b, F in enumerate(Fs):
+        L = ap.hop_length * (F - 1)
+        assert _snr_db(refs[b], wav[b, :L]) >= 40.0, b
+        assert np.abs(wav[b, L:]).max(initial=0.0) == 0.0
+    # bit-reproducible: no atomics in the overlap-add
+    wav2 = ap.griffin_lim_batch(mag, ph.cuda(), torch.tensor(Fs)).cpu().numpy()
+    np.testing.assert_array_equal(wav, wav2)
+
+
+def test_vocoder_argument_errors():
+    from tts_amd import _lib
+    lib = _lib.load()
+    x = torch.zeros(1, 4, 1025, device="cuda")
+    w = torch.zeros(1, 275 * 3, device="cuda")
+    bad = _lib.StftParams(1024, 275, 1100, 0)
+    rc = lib.ttsx_griffin_lim(_lib.ptr(x), _lib.ptr(x), None, 1, 4, bad, 1, 0.98, _lib.ptr(w), _lib.current_stream())
+    assert rc == _lib.ERR_ARG and b"n_fft" in lib.ttsx_last_error_string()

@@ -1,0 +1,56 @@
+// Shared helpers for the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/ttsx.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+void ttsx_set_error(const char* fmt, ...);
+
+#define TTSX_HIP(expr)                                                                     \
+  do {                                                                                     \
+    hipError_t e__ = (expr);                                                               \
+    if (e__ != hipSuccess) {                                                               \
+      ttsx_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e__)); \
+      return TTSX_ERR_HIP;                                                                 \
+    }                                                                                      \
+  } while (0)
+
+#define TTSX_ARG(cond, ...)        \
+  do {                             \
+    if (!(cond)) {                 \
+      ttsx_set_error(__VA_ARGS__); \
+      return TTSX_ERR_ARG;         \
+    }                              \
+  } while (0)
+
+#define TTSX_LAUNCH_CHECK() TTSX_HIP(hipGetLastError())
+
+__host__ __device__ static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+__host__ __device__ static inline int round_up(int a, int b) { return ceil_div(a, b) * b; }
+
+// Activation vectors that feed the row-block GEMMs are stored "quad-interleaved":
+// element k of utterance b lives at ((k/4) * Bpad + b) * 4 + (k%4), so that the four
+// consecutive k a lane needs for one MFMA fragment are a single 16-byte load and 16
+// neighbouring utterances are 256 contiguous bytes.
+__host__ __device__ static inline size_t qidx(int k, int b, int Bpad) {
+  return ((size_t)(k >> 2) * Bpad + b) * 4 + (k & 3);
+}
+
+__device__ static inline float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__device__ static inline float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ static inline float wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  return v;
+}

@@ -1,0 +1,288 @@
+"""Tacotron2 with the reference's Python surface, running on libttsx (gfx950).
+
+Mirrors `Tacotron2` of the reference (Tacotron2/TTS/models.py:727-813) for the
+serving path: constructor arguments, `load_state_dict`, `cuda`, `eval`,
+`decoder.max_decoder_steps`, `decoder.set_r`, `decoder.r` and
+`inference(text, speaker_ids=None)` with the same return tuple.  The decoder
+loop, attention, postnet run in hand-written HIP kernels through the C ABI;
+the encoder (embedding, 3 conv blocks, BiLSTM; once per utterance, <1 % of the
+time) uses stock PyTorch-ROCm ops.
+
+Extensions the reference does not have (its `inference` is batch-1 only,
+models.py:661): `inference_batch` decodes B utterances at once with
+per-utterance stop handling and optional length masking.
+"""
+import ctypes
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import _lib
+
+
+def _dev_tensor(v, device):
+    if isinstance(v, np.ndarray):
+        v = torch.from_numpy(np.ascontiguousarray(v))
+    return v.detach().to(device=device, dtype=torch.float32).contiguous()
+
+
+class _Decoder:
+    """The attributes of the reference `Decoder` that callers touch
+    (Tacotron2/TTS/models.py:474-483, 527-528; Synthesizer.load_tts sets
+    max_decoder_steps and calls set_r, Tacotron2/TTS/synthesizer.py:68-70)."""
+
+    def __init__(self, r):
+        self.r_init = r
+        self.r = r
+        self.memory_dim = 80
+        self.max_decoder_steps = 1000
+        self.stop_threshold = 0.7
+
+    def set_r(self, new_r):
+        self.r = new_r
+
+
+class Tacotron2:
+    def __init__(self, num_chars, num_speakers, r, postnet_output_dim=80, decoder_output_dim=80,
+                 attn_type="original", attn_win=False, attn_norm="softmax", prenet_type="original",
+                 prenet_dropout=True, forward_attn=False, trans_agent=False, forward_attn_mask=False,
+                 location_attn=True, attn_K=5, separate_stopnet=True, bidirectional_decoder=False):
+        if attn_type != "original":
+            if attn_type == "graves":
+                raise NotImplementedError("graves attention is outside the accelerated path")
+            raise RuntimeError(" [!] Given Attention Type '{attn_type}' is not exist.")
+        if attn_norm not in ("softmax", "sigmoid"):
+            raise ValueError("Unknown value for attention norm type")
+        if prenet_type not in ("original", "bn"):
+            raise ValueError("unknown prenet_type %r" % (prenet_type,))
+        for flag, name in ((attn_win, "windowing"), (forward_attn, "use_forward_attn"),
+                           (trans_agent, "transition_agent"), (bidirectional_decoder, "bidirectional_decoder"),
+                           (not location_attn, "location_attn=false"), (num_speakers > 1, "speaker embeddings")):
+            if flag:
+                raise NotImplementedError("%s is outside the accelerated path" % name)
+        if postnet_output_dim != 80 or decoder_output_dim != 80:
+            raise NotImplementedError("only 80 mel bins are supported")
+        self.num_chars = num_chars
+        self.n_frames_per_step = r
+        self.attn_norm = attn_norm
+        self.prenet_type = prenet_type
+        self.decoder = _Decoder(r)
+        self.device = torch.device("cpu")
+        self.training = False
+        self._sd = None
+        self._dec_handle = None
+        self._post_handle = None
+        self._lstm = None
+
+    # ---- torch.nn.Module look-alikes ------------------------------------
+    def load_state_dict(self, state_dict, strict=True):
+        sd = {}
+        for k, v in state_dict.items():
+            if k.endswith("num_batches_tracked"):
+                continue
+            sd[k] = v
+        need = ["embedding.weight", "decoder.attention_rnn.weight_ih", "decoder.decoder_rnn.weight_ih",
+                "decoder.linear_projection.linear_layer.weight", "postnet.convolutions.4.net.0.weight"]
+        missing = [k for k in need if k not in sd]
+        if missing:
+            raise RuntimeError("Missing key(s) in state_dict: %s" % ", ".join(missing))
+        rows = sd["decoder.linear_projection.linear_layer.weight"].shape[0]
+        if rows != 80 * self.decoder.r_init:
+            raise RuntimeError("size mismatch for decoder.linear_projection: %d rows, expected %d"
+                               % (rows, 80 * self.decoder.r_init))
+        self._sd_src = sd
+        self._release()
+        if self.device.type == "cuda":
+            self._upload()
+        return self
+
+    def cuda(self, device=None):
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        if getattr(self, "_sd_src", None) is not None:
+            self._upload()
+        return self
+
+    def to(self, device):
+        device = torch.device(device)
+        if device.type == "cuda":
+            return self.cuda(device.index)
+        self.device = device
+        return self
+
+    def eval(self):
+        self.training = False
+        return self
+
+    def train(self, mode=True):
+        if mode:
+            raise NotImplementedError("the accelerated path is inference-only")
+        return self
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
+
+    # ---- weights -----------------------------------------------------------
+    def _release(self):
+        if self._dec_handle is not None:
+            _lib.load().ttsx_t2_decoder_destroy(self._dec_handle)
+            self._dec_handle = None
+        if self._post_handle is not None:
+            _lib.load().ttsx_postnet_destroy(self._post_handle)
+            self._post_handle = None
+
+    def _upload(self):
+        lib = _lib.load()
+        self._release()
+        dev = self.device
+        sd = {k: _dev_tensor(v, dev) for k, v in self._sd_src.items()}
+        self._sd = sd
+        bn = self.prenet_type == "bn"
+        w = _lib.T2DecoderWeights()
+        for i in range(2):
+            p = "decoder.prenet.layers.%d." % i
+            w.prenet_w[i] = sd[p + "linear_layer.weight"].data_ptr()
+            w.prenet_bn_weight[i] = sd[p + "bn.weight"].data_ptr() if bn else None
+            w.prenet_bn_bias[i] = sd[p + "bn.bias"].data_ptr() if bn else None
+            w.prenet_bn_mean[i] = sd[p + "bn.running_mean"].data_ptr() if bn else None
+            w.prenet_bn_var[i] = sd[p + "bn.running_var"].data_ptr() if bn else None
+        g = lambda k: sd["decoder." + k].data_ptr()
+        w.attn_rnn_w_ih, w.attn_rnn_w_hh = g("attention_rnn.weight_ih"), g("attention_rnn.weight_hh")
+        w.attn_rnn_b_ih, w.attn_rnn_b_hh = g("attention_rnn.bias_ih"), g("attention_rnn.bias_hh")
+        w.query_w = g("attention.query_layer.linear_layer.weight")
+        w.inputs_w = g("attention.inputs_layer.linear_layer.weight")
+        w.v_w, w.v_b = g("attention.v.linear_layer.weight"), g("attention.v.linear_layer.bias")
+        w.loc_conv_w = g("attention.location_layer.location_conv.weight")
+        w.loc_dense_w = g("attention.location_layer.location_dense.linear_layer.weight")
+        w.dec_rnn_w_ih, w.dec_rnn_w_hh = g("decoder_rnn.weight_ih"), g("decoder_rnn.weight_hh")
+        w.dec_rnn_b_ih, w.dec_rnn_b_hh = g("decoder_rnn.bias_ih"), g("decoder_rnn.bias_hh")
+        w.proj_w, w.proj_b = g("linear_projection.linear_layer.weight"), g("linear_projection.linear_layer.bias")
+        w.stop_w, w.stop_b = g("stopnet.1.linear_layer.weight"), g("stopnet.1.linear_layer.bias")
+        handle = ctypes.c_void_p()
+        norm = _lib.NORM_SIGMOID if self.attn_norm == "sigmoid" else _lib.NORM_SOFTMAX
+        with torch.cuda.device(dev):
+            _lib.check(lib.ttsx_t2_decoder_create(ctypes.byref(w), self.decoder.r_init, norm,
+                                                  _lib.current_stream(), ctypes.byref(handle)),
+                       "ttsx_t2_decoder_create")
+            self._dec_handle = handle
+            pw = _lib.PostnetWeights()
+            for i in range(5):
+                p = "postnet.convolutions.%d.net." % i
+                pw.conv_w[i], pw.conv_b[i] = sd[p + "0.weight"].data_ptr(), sd[p + "0.bias"].data_ptr()
+                pw.bn_weight[i], pw.bn_bias[i] = sd[p + "1.weight"].data_ptr(), sd[p + "1.bias"].data_ptr()
+                pw.bn_mean[i], pw.bn_var[i] = sd[p + "1.running_mean"].data_ptr(), sd[p + "1.running_var"].data_ptr()
+            ph = ctypes.c_void_p()
+            _lib.check(lib.ttsx_postnet_create(ctypes.byref(pw), _lib.current_stream(), ctypes.byref(ph)),
+                       "ttsx_postnet_create")
+            self._post_handle = ph
+        # encoder BiLSTM as a stock module
+        lstm = torch.nn.LSTM(512, 256, num_layers=1, batch_first=True, bidirectional=True)
+        with torch.no_grad():
+            for name, _ in lstm.named_parameters():
+                getattr(lstm, name).copy_(sd["encoder.lstm." + name])
+        self._lstm = lstm.to(dev).eval()
+
+    def _require_device(self):
+        if self.device.type != "cuda" or self._dec_handle is None:
+            raise _lib.TtsxError("Tacotron2 runs on the GPU only: call .cuda() after load_state_dict() "
+                                 "(there is no CPU path)")
+
+    # ---- forward pieces ----------------------------------------------------
+    @torch.no_grad()
+    def encode(self, text):
+        """Embedding + Encoder.inference (Tacotron2/TTS/models.py:803-804, 449-454)."""
+        sd = self._sd
+        x = F.embedding(text, sd["embedding.weight"]).transpose(1, 2)
+        for i in range(3):
+            p = "encoder.convolutions.%d.net." % i
+            x = F.conv1d(x, sd[p + "0.weight"], sd[p + "0.bias"], padding=2)
+            x = F.batch_norm(x, sd[p + "1.running_mean"], sd[p + "1.running_var"], sd[p + "1.weight"],
+                             sd[p + "1.bias"], training=False, eps=1e-5)
+            x = torch.relu(x)
+        out, _ = self._lstm(x.transpose(1, 2).contiguous())
+        return out.contiguous()
+
+    @torch.no_grad()
+    def decode(self, enc, enc_len=None, fixed_steps=None):
+        """Greedy decoder loop on the GPU.  Returns (mel [B,F,80], align [B,S,T], stop [B,S],
+        n_steps [B] int32, steps_run)."""
+        lib = _lib.load()
+        B, T, _ = enc.shape
+        r = self.decoder.r
+        max_steps = int(fixed_steps) if fixed_steps else int(self.decoder.max_decoder_steps)
+        dev = enc.device
+        mel = torch.empty(B, max_steps * r, 80, device=dev, dtype=torch.float32)
+        align = torch.empty(B, max_steps, T, device=dev, dtype=torch.float32)
+        stop = torch.empty(B, max_steps, device=dev, dtype=torch.float32)
+        n_steps = torch.empty(B, device=dev, dtype=torch.int32)
+        steps_run = ctypes.c_int(0)
+        if enc_len is not None:
+            enc_len = enc_len.to(device=dev, dtype=torch.int32).contiguous()
+        with torch.cuda.device(dev):
+            _lib.check(lib.ttsx_t2_decoder_run(self._dec_handle, _lib.ptr(enc), _lib.ptr(enc_len), B, T, r,
+                                               max_steps, self.decoder.stop_threshold,
+                                               1 if fixed_steps else 0, _lib.ptr(mel), _lib.ptr(align),
+                                               _lib.ptr(stop), _lib.ptr(n_steps), ctypes.byref(steps_run),
+                                               _lib.current_stream()), "ttsx_t2_decoder_run")
+        s = steps_run.value
+        return mel[:, :s * r], align[:, :s], stop[:, :s], n_steps, s
+
+    @torch.no_grad()
+    def postnet(self, mel, n_frames=None):
+        """mel + Postnet(mel) (Tacotron2/TTS/models.py:809-810) on [B,F,80]."""
+        lib = _lib.load()
+        mel = mel.contiguous()
+        B, Fr, _ = mel.shape
+        out = torch.empty_like(mel)
+        if n_frames is not None:
+            n_frames = n_frames.to(device=mel.device, dtype=torch.int32).contiguous()
+        with torch.cuda.device(mel.device):
+            _lib.check(lib.ttsx_postnet_run(self._post_handle, _lib.ptr(mel), _lib.ptr(n_frames), B, Fr,
+                                            _lib.ptr(out), _lib.current_stream()), "ttsx_postnet_run")
+        return out
+
+    # ---- public API ----------------------------------------------------------
+    @torch.no_grad()
+    def inference(self, text, speaker_ids=None):
+        """Same contract as the reference `Tacotron2.inference`
+        (Tacotron2/TTS/models.py:802-813): text LongTensor [B,T] ->
+        (decoder_output [B,F,80], postnet_output [B,F,80], alignments [B,T_dec,T],
+        stop_tokens [B,T_dec,1])."""
+        if speaker_ids is not None:
+            raise NotImplementedError("speaker embeddings are outside the accelerated path")
+        out = self.inference_batch(text)
+        return out["decoder_output"], out["postnet_output"], out["alignments"], out["stop_tokens"]
+
+    @torch.no_grad()
+    def inference_batch(self, text, text_lengths=None, fixed_steps=None):
+        """Batched decode.  Each utterance's rows up to n_steps[b] equal what a
+        batch-1 `inference` of that utterance returns; later rows are padding."""
+        self._require_device()
+        text = torch.as_tensor(text).to(self.device).long()
+        if text.dim() != 2:
+            raise ValueError("text must be [B, T]")
+        enc = self.encode(text)
+        mel, align, stop, n_steps, steps = self.decode(enc, text_lengths, fixed_steps)
+        if not fixed_steps and steps == self.decoder.max_decoder_steps and \
+                bool((stop[:, -1] <= self.decoder.stop_threshold).any()):
+            print("   | > Decoder stopped with 'max_decoder_steps")
+        n_frames = (n_steps * self.decoder.r) if text.shape[0] > 1 else None
+        post = self.postnet(mel, n_frames)
+        return dict(decoder_output=mel, postnet_output=post, alignments=align,
+                    stop_tokens=stop.unsqueeze(-1), n_steps=n_steps, encoder_outputs=enc)
+
+
+def setup_model(num_chars, num_speakers, c):
+    """Counterpart of `setup_model` (Tacotron2/TTS/utils.py:1267-1286)."""
+    print("\t[-] Using model: {}".format(c.model))
+    return Tacotron2(num_chars=num_chars, num_speakers=num_speakers, r=c.r,
+                     postnet_output_dim=c.audio["num_mels"], decoder_output_dim=c.audio["num_mels"],
+                     attn_type=c.attention_type, attn_win=c.windowing, attn_norm=c.attention_norm,
+                     prenet_type=c.prenet_type, prenet_dropout=c.prenet_dropout,
+                     forward_attn=c.use_forward_attn, trans_agent=c.transition_agent,
+                     forward_attn_mask=c.forward_attn_mask, location_attn=c.location_attn,
+                     attn_K=c.attention_heads, separate_stopnet=c.separate_stopnet,
+                     bidirectional_decoder=c.bidirectional_decoder)
