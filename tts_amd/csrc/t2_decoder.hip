@@ -1,24 +1,37 @@
-// Tacotron2 decoder for gfx950: row-block fp32-MFMA GEMMs (LSTM gates, query, projection),
-// location-sensitive attention, prenet + stopnet, and the greedy loop around them.
+// Tacotron2 decoder for gfx950.
 //
-// What it computes per step follows Decoder.decode (Tacotron2/TTS/models.py:578-617):
-//   x2  = prenet(memory)                        K1
-//   h_a = LSTMCell([x2; ctx], h_a, c_a)         K2
-//   q   = W_q h_a                               K3
-//   a   = norm(v . tanh(q + loc(a_prev, a_cum) + P))   K4-K6
-//   ctx = a . enc ; a_cum += a                  K7
-//   h_d = LSTMCell([h_a; ctx], h_d, c_d)        K8
-//   o   = W_o [h_d; ctx] + b_o                  K9
-//   stop = sigmoid(w_s [h_d; o] + b_s)          K10
+// What it computes per step follows Decoder.decode (Tacotron2/TTS/models.py:578-617) with
+// Prenet (:76-82), OriginalAttention.forward (:314-361), LocationLayer (:84-104) and the
+// greedy loop of Decoder.inference (:643-673):
+//   x2  = prenet(memory)
+//   h_a = LSTMCell([x2; ctx], h_a, c_a)
+//   q   = W_q h_a
+//   a   = norm(v . tanh(q + W_ld conv1d([a_prev; a_cum]) + P) + b_v) ; a_cum += a
+//   ctx = a . enc
+//   h_d = LSTMCell([h_a; ctx], h_d, c_d)
+//   o   = W_o [h_d; ctx] + b_o ;  stop = sigmoid(w_s [h_d; o] + b_s)
 //
-// Data layout.  Weights are packed once: 16 output rows form a row block; inside a row
-// block the K axis is cut in groups of 16 and each group is stored as 64 lanes x 4 floats
-// in exactly the order mfma_f32_16x16x4f32 wants its A operand over four consecutive
-// issues (lane l: row l&15, k = 4*(l>>4) + s for issue s).  A wave therefore streams its
-// weights with one fully coalesced 1 KiB load per 16 k.  LSTM gate rows are interleaved so
-// that row 4u+g of a block is gate g (i,f,g,o) of hidden unit u: after the MFMA the four
+// Launches per step (all stream-ordered, captured into a hipGraph per chunk of steps):
+//   prenet layer 2 | attention LSTM | query | energies | normalise+context | decoder LSTM | projection
+// The projection launch carries, besides the 80*r_init mel rows, two sets of composed rows so
+// that nothing else sits on the serial path between two steps:
+//   * one row  u = [w_s,h + W_o,h^T w_s,o ; W_o,c^T w_s,o]  whose product with [h_d; ctx] is the
+//     stopnet logit (w_s [h_d; o] + b_s with o substituted), and
+//   * 256 rows (A1 W_o[last frame rows]) whose product is the pre-activation of prenet layer 1
+//     for the NEXT step (prenet layer 1 is linear in the fed-back frame; BatchNorm folded).
+// Both are exact algebraic rewrites; rounding differs from the reference at the 1e-6 level.
+//
+// Layouts.  Weights are packed once: 16 output rows form a row block; inside a row block the
+// K axis is cut in groups of 16 and each group is stored as 64 lanes x 4 floats in the order
+// v_mfma_f32_16x16x4_f32 wants its A operand over four consecutive issues (lane l: row l&15,
+// k = 4*(l>>4) + s for issue s), so a wave streams weights with fully coalesced 1 KiB loads.
+// LSTM gate rows are interleaved (row 4u+g of a block = gate g of hidden unit u): the four
 // accumulator registers of a lane are the four gates of one (unit, utterance) pair and the
-// cell update is lane-local.  Activations are quad-interleaved (see qidx in common.h).
+// cell update is lane-local.  Activations are quad-interleaved (qidx in common.h).
+//
+// Two engines share the packed weights: B <= 2 utterances run a GEMV engine (weights straight
+// to VGPRs with every load of a wave in flight at once, activations staged in LDS; this regime
+// is HBM-bandwidth bound), larger batches run the fp32 MFMA engine.
 #include <algorithm>
 #include <vector>
 
@@ -26,25 +39,33 @@
 
 namespace {
 
-struct Ctrl {
-  int base;      // decoder steps completed before the current chunk (state parity, t == 0 test)
+struct RunCtx {
+  int base;      // decoder steps completed before the current chunk (state parity)
   int out_base;  // output row of the chunk's first step
-  int all_done;  // set when every utterance has emitted its stop frame (free-running mode)
+  int all_done;  // every utterance has emitted its stop frame (free-running mode)
   int n_done;
+  int B, T, r, free_running;
+  float threshold;
+  int mel_rows, align_rows, stop_rows;
+  float* mel;        // [B, mel_rows, 80]
+  float* align;      // [B, align_rows, T]
+  float* stop;       // [B, stop_rows]
+  int32_t* n_steps;  // [B]
+  const float* enc;  // [B, T, 512]
+  const int32_t* enc_len;
 };
 
 constexpr int ENC_DIM = 512, QUERY_DIM = 1024, DEC_DIM = 1024, PRENET_DIM = 256, ATT_DIM = 128;
 constexpr int MEL_DIM = 80, LOC_F = 32, LOC_K = 31;
 constexpr int GEMM_THREADS = 512, GEMM_WAVES = GEMM_THREADS / 64;
+constexpr int GEMV_MAX_B = 2;
 
 // ------------------------------------------------------------------ weight packing
-// dst[((rb*KG + kg)*64 + lane)*4 + s] = src_row(rb*16 + (lane&15))[kg*16 + 4*(lane>>4) + s]
-// where the source row is the concatenation [w1 row | w2 row], optionally scaled per row.
-// lstm_hidden > 0 selects gate interleaving: packed row p of block rb <- source row
-// (p&3)*hidden + 4*rb + (p>>2).
+// dst[((rb*KG + kg)*64 + lane)*4 + s] = src(row)[kg*16 + 4*(lane>>4) + s], row = rb*16 + (lane&15)
+// (or, with lstm_hidden > 0, packed row p of block rb <- source row (p&3)*hidden + 4*rb + (p>>2)).
+// The source row is the concatenation [w1 row | w2 row].
 __global__ void pack_rows_kernel(float* __restrict__ dst, const float* __restrict__ w1, int k1,
-                                 const float* __restrict__ w2, int k2, int rows, int KG, int lstm_hidden,
-                                 const float* __restrict__ row_scale) {
+                                 const float* __restrict__ w2, int k2, int rows, int KG, int lstm_hidden) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   size_t total = (size_t)ceil_div(rows, 16) * KG * 256;
   if (i >= total) return;
@@ -58,7 +79,6 @@ __global__ void pack_rows_kernel(float* __restrict__ dst, const float* __restric
   if (row < rows) {
     if (k < k1) v = w1[(size_t)row * k1 + k];
     else if (k - k1 < k2) v = w2[(size_t)row * k2 + (k - k1)];
-    if (row_scale) v *= row_scale[row];
   }
   dst[i] = v;
 }
@@ -78,10 +98,10 @@ __global__ void pack_bias_kernel(float* __restrict__ dst, const float* __restric
   dst[i] = v;
 }
 
-// Prenet layer with eval-mode BatchNorm folded in: wt[k][n] = w[n][k]*g[n]/sqrt(var[n]+eps),
-// bias[n] = beta[n] - mean[n]*g[n]/sqrt(var[n]+eps); stored transposed so that thread n reads
-// consecutive addresses.  Without BatchNorm ("original" prenet) scale = 1, bias = 0.
-__global__ void pack_prenet_kernel(float* __restrict__ wt, float* __restrict__ bias, const float* __restrict__ w,
+// Prenet layer with eval-mode BatchNorm folded in (row-major [n_out][n_in]):
+// wf[n][k] = w[n][k]*g[n]/sqrt(var[n]+eps), bf[n] = beta[n] - mean[n]*g[n]/sqrt(var[n]+eps).
+// Without BatchNorm ("original" prenet, bias-free Linear) the scale is 1 and the bias 0.
+__global__ void fold_prenet_kernel(float* __restrict__ wf, float* __restrict__ bf, const float* __restrict__ w,
                                    const float* __restrict__ g, const float* __restrict__ beta,
                                    const float* __restrict__ mean, const float* __restrict__ var, int n_out,
                                    int n_in) {
@@ -90,11 +110,48 @@ __global__ void pack_prenet_kernel(float* __restrict__ wt, float* __restrict__ b
   int n = i / n_in, k = i % n_in;
   float sc = 1.f;
   if (g) sc = g[n] / sqrtf(var[n] + 1e-5f);
-  wt[(size_t)k * n_out + n] = w[i] * sc;
-  if (k == 0) bias[n] = g ? beta[n] - mean[n] * sc : 0.f;
+  wf[i] = w[i] * sc;
+  if (k == 0) bf[n] = g ? beta[n] - mean[n] * sc : 0.f;
 }
 
-// ------------------------------------------------------------------ row-block GEMM
+// Rows of the projection launch beyond the mel rows (fp64 accumulation, done once per r):
+//   ext_w[0]        = [w_s,h + W_o,h^T w_s,o ; W_o,c^T w_s,o],  ext_b[0] = w_s,o . b_o + b_s
+//   ext_w[1..15]    = 0
+//   ext_w[16 + n]   = sum_j A1f[n][j] W_o[80(r-1)+j][:],        ext_b[16+n] = sum_j A1f[n][j] b_o[80(r-1)+j] + b1f[n]
+__global__ void compose_proj_ext_kernel(float* __restrict__ ext_w, float* __restrict__ ext_b,
+                                        const float* __restrict__ proj_w, const float* __restrict__ proj_b,
+                                        const float* __restrict__ stop_w, const float* __restrict__ stop_b,
+                                        const float* __restrict__ a1f, const float* __restrict__ b1f, int odim,
+                                        int r) {
+  const int K = DEC_DIM + ENC_DIM;
+  const int row = blockIdx.x;  // 0 .. 16+255
+  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    double acc = 0.0;
+    if (row == 0) {
+      for (int j = 0; j < odim; ++j) acc += (double)stop_w[DEC_DIM + j] * (double)proj_w[(size_t)j * K + k];
+      if (k < DEC_DIM) acc += (double)stop_w[k];
+    } else if (row >= 16) {
+      const int n = row - 16;
+      for (int j = 0; j < MEL_DIM; ++j)
+        acc += (double)a1f[n * MEL_DIM + j] * (double)proj_w[(size_t)(MEL_DIM * (r - 1) + j) * K + k];
+    }
+    ext_w[(size_t)row * K + k] = (float)acc;
+  }
+  if (threadIdx.x == 0) {
+    double acc = 0.0;
+    if (row == 0) {
+      for (int j = 0; j < odim; ++j) acc += (double)stop_w[DEC_DIM + j] * (double)proj_b[j];
+      acc += (double)stop_b[0];
+    } else if (row >= 16) {
+      const int n = row - 16;
+      for (int j = 0; j < MEL_DIM; ++j) acc += (double)a1f[n * MEL_DIM + j] * (double)proj_b[MEL_DIM * (r - 1) + j];
+      acc += (double)b1f[n];
+    }
+    ext_b[row] = (float)acc;
+  }
+}
+
+// ------------------------------------------------------------------ GEMM / GEMV engines
 struct Seg {
   const float* x[2];  // quad-interleaved activation buffer(s)
   int sel;            // 0: x[0]; 1: x[step&1] (state before this step); 2: x[(step+1)&1] (new state)
@@ -107,19 +164,69 @@ struct GemmP {
   const float* Wp;
   const float* bias;
   Seg seg[3];
-  int nseg, KG, Bpad, B;
+  int nseg, KG, Bpad;
   float* out[2];  // LINEAR/PROJ: out[0] quad layout; LSTM: h ping-pong pair, written at (step+1)&1
   float* c;       // LSTM cell state, quad layout
-  float* mel;     // PROJ: [B, mel_rows, 80]
-  int r, rows, mel_rows;
-  const Ctrl* ctrl;
+  float* x1;      // PROJ: prenet layer-1 activations for the next step, quad layout
+  int relu;       // LINEAR: apply ReLU
+  int o_quads;    // PROJ: number of quads that are mel rows (80*r_init/4)
+  RunCtx* ctx;
   int step_in_chunk;
 };
 
+// Finish one quad (4 consecutive output rows, bias already added) of utterance column b.
+template <int MODE>
+__device__ inline void epilogue_quad(const GemmP& p, int step, int quad, int b, f32x4 v) {
+  const int Bpad = p.Bpad;
+  if (MODE == MODE_LSTM) {
+    // the four rows are gates i,f,g,o of hidden unit `quad`
+    const size_t idx = qidx(quad, b, Bpad);
+    const float c_old = p.c[idx];
+    const float c_new = sigmoidf_(v[1]) * c_old + sigmoidf_(v[0]) * tanhf(v[2]);
+    const float h_new = sigmoidf_(v[3]) * tanhf(c_new);
+    p.c[idx] = c_new;
+    p.out[(step + 1) & 1][idx] = h_new;
+  } else if (MODE == MODE_LINEAR) {
+    if (p.relu) v = (f32x4){fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+    reinterpret_cast<float4*>(p.out[0])[(size_t)quad * Bpad + b] = make_float4(v[0], v[1], v[2], v[3]);
+  } else {
+    RunCtx* cx = p.ctx;
+    if (quad < p.o_quads) {
+      reinterpret_cast<float4*>(p.out[0])[(size_t)quad * Bpad + b] = make_float4(v[0], v[1], v[2], v[3]);
+      if (b < cx->B && quad * 4 < cx->r * MEL_DIM) {
+        // frames of this step, frame-major [B, mel_rows, 80]: o[j] -> frame j/80, bin j%80
+        const int row0 = (cx->out_base + p.step_in_chunk) * cx->r;
+        float* dst = cx->mel + ((size_t)b * cx->mel_rows + row0) * MEL_DIM + quad * 4;
+        *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    } else if (quad < p.o_quads + 4) {
+      if (quad == p.o_quads && b < cx->B) {
+        const float s = sigmoidf_(v[0]);
+        cx->stop[(size_t)b * cx->stop_rows + cx->out_base + p.step_in_chunk] = s;
+        if (s > cx->threshold && cx->n_steps[b] == 0) {
+          cx->n_steps[b] = step + 1;  // steps run so far, the stop frame included
+          const int done = atomicAdd(&cx->n_done, 1) + 1;
+          if (cx->free_running && done == cx->B) cx->all_done = 1;
+        }
+      }
+    } else {
+      const int xq = quad - p.o_quads - 4;
+      reinterpret_cast<float4*>(p.x1)[(size_t)xq * Bpad + b] =
+          make_float4(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f));
+    }
+  }
+}
+
+__device__ inline const float* seg_ptr(const Seg& sg, int step) {
+  return sg.sel == 0 ? sg.x[0] : sg.x[(step + (sg.sel == 2)) & 1];
+}
+
+// fp32 MFMA engine: one row block x NT column tiles of 16 utterances per workgroup, the K axis
+// split over the 8 waves, partial tiles combined through LDS.
 template <int NT, int MODE>
 __global__ __launch_bounds__(GEMM_THREADS) void rowblock_gemm_kernel(GemmP p) {
-  if (p.ctrl->all_done) return;
-  const int step = p.ctrl->base + p.step_in_chunk;
+  if (p.ctx->all_done) return;
+  const int step = p.ctx->base + p.step_in_chunk;
   const int rb = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int b0 = blockIdx.y * (NT * 16);
   __shared__ f32x4 red[GEMM_WAVES][NT][64];
@@ -131,17 +238,36 @@ __global__ __launch_bounds__(GEMM_THREADS) void rowblock_gemm_kernel(GemmP p) {
   const float4* W = reinterpret_cast<const float4*>(p.Wp) + (size_t)rb * p.KG * 64 + lane;
   const int col = b0 + (lane & 15);
   const int kq = lane >> 4;
+  constexpr int U = NT >= 3 ? 2 : 4;  // k-groups whose loads are issued together
   int kg_base = 0;
   for (int s = 0; s < p.nseg; ++s) {
     const Seg sg = p.seg[s];
-    const float* xb = sg.sel == 0 ? sg.x[0] : sg.x[(step + (sg.sel == 2)) & 1];
-    const float4* X = reinterpret_cast<const float4*>(xb) + (size_t)kq * p.Bpad + col;
-#pragma unroll 4
-    for (int kg = wave; kg < sg.kgroups; kg += GEMM_WAVES) {
+    const float4* X = reinterpret_cast<const float4*>(seg_ptr(sg, step)) + (size_t)kq * p.Bpad + col;
+    const size_t xs = (size_t)4 * p.Bpad;
+    int kg = wave;
+    for (; kg + (U - 1) * GEMM_WAVES < sg.kgroups; kg += U * GEMM_WAVES) {
+      float4 wv[U], xv[U][NT];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        wv[u] = W[(size_t)(kg_base + kg + u * GEMM_WAVES) * 64];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) xv[u][n] = X[(size_t)(kg + u * GEMM_WAVES) * xs + n * 16];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[u].x, xv[u][n].x, acc[n], 0, 0, 0);
+          acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[u].y, xv[u][n].y, acc[n], 0, 0, 0);
+          acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[u].z, xv[u][n].z, acc[n], 0, 0, 0);
+          acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[u].w, xv[u][n].w, acc[n], 0, 0, 0);
+        }
+    }
+    for (; kg < sg.kgroups; kg += GEMM_WAVES) {
       const float4 wv = W[(size_t)(kg_base + kg) * 64];
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
-        const float4 xv = X[(size_t)kg * 4 * p.Bpad + n * 16];
+        const float4 xv = X[(size_t)kg * xs + n * 16];
         acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.x, xv.x, acc[n], 0, 0, 0);
         acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.y, xv.y, acc[n], 0, 0, 0);
         acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.z, xv.z, acc[n], 0, 0, 0);
@@ -154,312 +280,319 @@ __global__ __launch_bounds__(GEMM_THREADS) void rowblock_gemm_kernel(GemmP p) {
   for (int n = 0; n < NT; ++n) red[wave][n][lane] = acc[n];
   __syncthreads();
 
-  // wave w finishes n-tiles w, w+8, ...: lane l holds rows 4*(l>>4)+{0..3} of column l&15
+  // wave w finishes n-tile w: lane l holds rows 4*(l>>4)+{0..3} of column l&15
   for (int n = wave; n < NT; n += GEMM_WAVES) {
     f32x4 v = red[0][n][lane];
 #pragma unroll
     for (int w = 1; w < GEMM_WAVES; ++w) v += red[w][n][lane];
     const int b = b0 + n * 16 + (lane & 15);
-    const int quad = rb * 4 + (lane >> 4);  // output rows 4*quad .. 4*quad+3
+    const int quad = rb * 4 + (lane >> 4);
     const float4 bias = reinterpret_cast<const float4*>(p.bias)[quad];
     v[0] += bias.x, v[1] += bias.y, v[2] += bias.z, v[3] += bias.w;
-    if (MODE == MODE_LSTM) {
-      // rows of this lane = gates i,f,g,o of hidden unit `quad`
-      const size_t ci = qidx(quad, b, p.Bpad);
-      const float c_old = p.c[ci];
-      const float c_new = sigmoidf_(v[1]) * c_old + sigmoidf_(v[0]) * tanhf(v[2]);
-      const float h_new = sigmoidf_(v[3]) * tanhf(c_new);
-      p.c[ci] = c_new;
-      p.out[(step + 1) & 1][ci] = h_new;
-    } else {
-      reinterpret_cast<float4*>(p.out[0])[(size_t)quad * p.Bpad + b] = make_float4(v[0], v[1], v[2], v[3]);
-      if (MODE == MODE_PROJ && b < p.B && quad * 4 < p.r * MEL_DIM) {
-        // frames of this step, frame-major [B, mel_rows, 80]: o[j] -> frame j/80, bin j%80
-        const int row0 = (p.ctrl->out_base + p.step_in_chunk) * p.r;
-        float* dst = p.mel + ((size_t)b * p.mel_rows + row0) * MEL_DIM + quad * 4;
-        *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-      }
-    }
+    epilogue_quad<MODE>(p, step, quad, b, v);
   }
 }
 
-// ------------------------------------------------------------------ prenet + stopnet
-struct PrenetP {
-  const float* w1t;  // [80][256]
-  const float* b1;
-  const float* w2t;  // [256][256]
-  const float* b2;
-  const float* stop_w;  // [1024 + 80*r_init]
-  const float* stop_b;
-  const float* h_d[2];  // quad
-  const float* o;       // quad [80*r_init]
-  const float* mem_override;  // [B,80] row-major or null
-  float* x2;            // quad [256]
-  float* stop_out;      // [B, stop_rows]
-  int32_t* n_steps;     // [B]
-  Ctrl* ctrl;
-  int step_in_chunk, Bpad, B, r, r_init, stop_rows;
-  int do_stop;    // evaluate the stop token of step-1 (needs step > 0)
-  int do_prenet;  // compute x2 for `step`
-  int free_running;
-  float threshold;
-};
+// GEMV engine for NB <= 2 utterances (Bpad == NB): every weight load of a wave is issued before
+// the first use, activations come from LDS.  KGW = k-groups per wave (KG / 8).
+template <int NB, int KGW, int MODE>
+__global__ __launch_bounds__(GEMM_THREADS) void rowblock_gemv_kernel(GemmP p) {
+  if (p.ctx->all_done) return;
+  const int step = p.ctx->base + p.step_in_chunk;
+  const int rb = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, tid = threadIdx.x;
+  constexpr int KG = KGW * GEMM_WAVES;
+  __shared__ float4 s_x[KG * 4 * NB];  // quad-interleaved: [quad][b]
+  __shared__ float s_red[GEMM_WAVES][NB][16];
 
-__global__ __launch_bounds__(256) void prenet_stop_kernel(PrenetP p) {
-  if (p.ctrl->all_done) return;
-  const int step = p.ctrl->base + p.step_in_chunk;
-  const int b = blockIdx.x, tid = threadIdx.x;
-  __shared__ float sm[MEL_DIM];
-  __shared__ float sx1[PRENET_DIM];
-  __shared__ float sred[4];
-  const int odim = MEL_DIM * p.r_init;
+  // issue the weight stream first
+  const float4* W = reinterpret_cast<const float4*>(p.Wp) + (size_t)rb * KG * 64 + lane;
+  float4 wv[KGW];
+#pragma unroll
+  for (int i = 0; i < KGW; ++i) {
+#ifdef TTSX_NT_WEIGHTS
+    wv[i] = __builtin_nontemporal_load(W + (size_t)(wave + i * GEMM_WAVES) * 64);
+#else
+    wv[i] = W[(size_t)(wave + i * GEMM_WAVES) * 64];
+#endif
+  }
 
-  if (p.do_stop && step > 0) {
-    // stop token of the step that just finished: sigmoid(w_s . [h_d; o] + b_s)
-    const float* hd = p.h_d[step & 1];
-    float acc = 0.f;
-    for (int k = tid; k < DEC_DIM; k += 256) acc += p.stop_w[k] * hd[qidx(k, b, p.Bpad)];
-    for (int k = tid; k < odim; k += 256) acc += p.stop_w[DEC_DIM + k] * p.o[qidx(k, b, p.Bpad)];
-    acc = wave_sum(acc);
-    if ((tid & 63) == 0) sred[tid >> 6] = acc;
-    __syncthreads();
-    if (tid == 0) {
-      const float s = sigmoidf_(sred[0] + sred[1] + sred[2] + sred[3] + p.stop_b[0]);
-      const int row = p.ctrl->out_base + p.step_in_chunk - 1;
-      p.stop_out[(size_t)b * p.stop_rows + row] = s;
-      if (s > p.threshold && p.n_steps[b] == 0) {
-        p.n_steps[b] = step;  // steps run so far, the stop frame included
-        const int done = atomicAdd(&p.ctrl->n_done, 1) + 1;
-        if (p.free_running && done == p.B) p.ctrl->all_done = 1;
-      }
+  // stage the activations (segments are already quad-interleaved with Bpad == NB)
+  {
+    int q0 = 0;
+    for (int s = 0; s < p.nseg; ++s) {
+      const Seg sg = p.seg[s];
+      const float4* X = reinterpret_cast<const float4*>(seg_ptr(sg, step));
+      const int n = sg.kgroups * 4 * NB;
+      for (int i = tid; i < n; i += GEMM_THREADS) s_x[q0 + i] = X[i];
+      q0 += n;
     }
   }
-  if (!p.do_prenet) return;
+  __syncthreads();
 
-  // memory = last of the r frames emitted by the previous step (zeros before the first)
-  if (tid < MEL_DIM) {
-    float m = 0.f;
-    if (p.mem_override) m = p.mem_override[b * MEL_DIM + tid];
-    else if (step > 0) m = p.o[qidx(MEL_DIM * (p.r - 1) + tid, b, p.Bpad)];
-    sm[tid] = m;
+  float acc[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) acc[b] = 0.f;
+  const int kq = lane >> 4;
+#pragma unroll
+  for (int i = 0; i < KGW; ++i) {
+    const int quad = (wave + i * GEMM_WAVES) * 4 + kq;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const float4 xv = s_x[quad * NB + b];
+      acc[b] += wv[i].x * xv.x + wv[i].y * xv.y + wv[i].z * xv.z + wv[i].w * xv.w;
+    }
+  }
+  // lanes l, l^16, l^32, l^48 hold partial sums of the same row
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    acc[b] += __shfl_xor(acc[b], 16, 64);
+    acc[b] += __shfl_xor(acc[b], 32, 64);
+    if (lane < 16) s_red[wave][b][lane] = acc[b];
   }
   __syncthreads();
-  float a1 = p.b1[tid];
-#pragma unroll 8
-  for (int k = 0; k < MEL_DIM; ++k) a1 += p.w1t[k * PRENET_DIM + tid] * sm[k];
-  sx1[tid] = fmaxf(a1, 0.f);
-  __syncthreads();
-  float a2 = p.b2[tid];
-#pragma unroll 8
-  for (int k = 0; k < PRENET_DIM; ++k) a2 += p.w2t[k * PRENET_DIM + tid] * sx1[k];
-  p.x2[qidx(tid, b, p.Bpad)] = fmaxf(a2, 0.f);
+  if (tid < 4 * NB) {
+    const int qi = tid / NB, b = tid % NB;  // quad inside the row block, utterance
+    const int quad = rb * 4 + qi;
+    f32x4 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < GEMM_WAVES; ++w) t += s_red[w][b][qi * 4 + j];
+      v[j] = t;
+    }
+    const float4 bias = reinterpret_cast<const float4*>(p.bias)[quad];
+    v[0] += bias.x, v[1] += bias.y, v[2] += bias.z, v[3] += bias.w;
+    epilogue_quad<MODE>(p, step, quad, b, v);
+  }
 }
 
 // ------------------------------------------------------------------ attention
 struct AttnP {
   const float* q;        // quad [128]
-  const float* P;        // [B][128][T]  processed_inputs, transposed
-  const float* enc;      // [B][T][512]
-  const int32_t* enc_len;
+  const float* P;        // [B][T][128]  processed_inputs
   const float* loc_conv_w;   // [32][2][31]
   const float* loc_dense_w;  // [128][32]
   const float* v_w;          // [128]
   const float* v_b;          // [1]
   float* a_prev;         // [B][T]
   float* a_cum;          // [B][T]
-  float* ctx;            // quad [512]
-  float* align_out;      // [B][align_rows][T]
-  const Ctrl* ctrl;
-  int step_in_chunk, Bpad, T, align_rows, norm;
+  float* energies;       // [B][T]
+  float* ctx_out;        // quad [512]
+  RunCtx* ctx;
+  int step_in_chunk, Bpad, norm;
 };
 
-constexpr int ATT_THREADS = 512, ATT_TT = 128, ATT_PAD = (LOC_K - 1) / 2;
+constexpr int EN_TT = 32, EN_THREADS = 512, ATT_PAD = (LOC_K - 1) / 2;
 
-__device__ inline float block_reduce_sum(float v, float* sred, int tid) {
-  v = wave_sum(v);
-  __syncthreads();
-  if ((tid & 63) == 0) sred[tid >> 6] = v;
-  __syncthreads();
-  float t = 0.f;
-#pragma unroll
-  for (int w = 0; w < ATT_THREADS / 64; ++w) t += sred[w];
-  return t;
-}
-__device__ inline float block_reduce_max(float v, float* sred, int tid) {
-  v = wave_max(v);
-  __syncthreads();
-  if ((tid & 63) == 0) sred[tid >> 6] = v;
-  __syncthreads();
-  float t = sred[0];
-#pragma unroll
-  for (int w = 1; w < ATT_THREADS / 64; ++w) t = fmaxf(t, sred[w]);
-  return t;
-}
+// energies e[b][t] for a tile of 32 encoder positions:
+//   cf[t][f] = sum_{c,j} W_lc[f][c][j] * a_c[t + j - 15]         (thread: filter f, 2 positions)
+//   e[t] = b_v + sum_d v[d] * tanh(q[d] + sum_f W_ld[d][f] cf[t][f] + P[t][d])   (thread: dim d, 8 positions)
+__global__ __launch_bounds__(EN_THREADS) void energy_kernel(AttnP p) {
+  const RunCtx* cx = p.ctx;
+  if (cx->all_done) return;
+  const int T = cx->T, b = blockIdx.y, t0 = blockIdx.x * EN_TT, tid = threadIdx.x;
+  __shared__ float s_a[2][EN_TT + 2 * ATT_PAD + 2];
+  __shared__ __attribute__((aligned(16))) float s_cf[EN_TT][LOC_F];
+  __shared__ float s_q[ATT_DIM];
+  __shared__ float s_part[2][EN_TT];
 
-__global__ __launch_bounds__(ATT_THREADS) void attention_kernel(AttnP p) {
-  if (p.ctrl->all_done) return;
-  const int b = blockIdx.x, tid = threadIdx.x, T = p.T;
-  const int len = p.enc_len ? p.enc_len[b] : T;
-  extern __shared__ float smem[];
-  float* s_prev = smem;                      // [T + 30], zero padded by 15 each side
-  float* s_cum = s_prev + (T + 2 * ATT_PAD);  // [T + 30]
-  float* s_e = s_cum + (T + 2 * ATT_PAD);     // [T]
-  float* s_cf = s_e + T;                      // [128][33]
-  float* s_part = s_cf + ATT_TT * (LOC_F + 1);  // [4][128]
-  float* s_q = s_part + 4 * ATT_TT;             // [128]
-  float* s_red = s_q + ATT_DIM;                 // [8]
-
-  for (int i = tid; i < T + 2 * ATT_PAD; i += ATT_THREADS) {
-    const int t = i - ATT_PAD;
-    const bool in = t >= 0 && t < T;
-    s_prev[i] = in ? p.a_prev[(size_t)b * T + t] : 0.f;
-    s_cum[i] = in ? p.a_cum[(size_t)b * T + t] : 0.f;
+  if (tid < 2 * (EN_TT + 2 * ATT_PAD)) {
+    const int c = tid / (EN_TT + 2 * ATT_PAD), i = tid % (EN_TT + 2 * ATT_PAD);
+    const int t = t0 + i - ATT_PAD;
+    const float* src = c == 0 ? p.a_prev : p.a_cum;
+    s_a[c][i] = (t >= 0 && t < T) ? src[(size_t)b * T + t] : 0.f;
+  } else if (tid >= 256 && tid < 256 + ATT_DIM) {
+    s_q[tid - 256] = p.q[qidx(tid - 256, b, p.Bpad)];
   }
-  if (tid < ATT_DIM) s_q[tid] = p.q[qidx(tid, b, p.Bpad)];
   __syncthreads();
-
-  const int tl = tid & (ATT_TT - 1);  // position inside the tile
-  const int grp = tid >> 7;           // 0..3, wave-uniform
-  const float vb = p.v_b[0];
-  for (int t0 = 0; t0 < T; t0 += ATT_TT) {
-    const int t = t0 + tl;
-    // location conv: filters grp*8 .. grp*8+7 at position t
-    {
-      float win[2][LOC_K];
+  {
+    // location conv: filter f, positions tp*2, tp*2+1
+    const int f = tid & 31, tp = tid >> 5;  // tp 0..15
+    const float* w = p.loc_conv_w + f * 2 * LOC_K;
+    float acc0 = 0.f, acc1 = 0.f;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      float win[LOC_K + 1];
+#pragma unroll
+      for (int j = 0; j < LOC_K + 1; ++j) win[j] = s_a[c][tp * 2 + j];
 #pragma unroll
       for (int j = 0; j < LOC_K; ++j) {
-        const int i = min(t + j, T + 2 * ATT_PAD - 1);
-        win[0][j] = s_prev[i];
-        win[1][j] = s_cum[i];
-      }
-#pragma unroll
-      for (int ff = 0; ff < 8; ++ff) {
-        const int f = grp * 8 + ff;
-        const float* w = p.loc_conv_w + f * 2 * LOC_K;
-        float acc = 0.f;
-#pragma unroll
-        for (int j = 0; j < LOC_K; ++j) acc += w[j] * win[0][j];
-#pragma unroll
-        for (int j = 0; j < LOC_K; ++j) acc += w[LOC_K + j] * win[1][j];
-        s_cf[tl * (LOC_F + 1) + f] = acc;
+        const float wj = w[c * LOC_K + j];
+        acc0 += wj * win[j];
+        acc1 += wj * win[j + 1];
       }
     }
-    __syncthreads();
-    // energies: attention dims grp*32 .. grp*32+31 at position t
-    {
-      float cf[LOC_F];
-#pragma unroll
-      for (int f = 0; f < LOC_F; ++f) cf[f] = s_cf[tl * (LOC_F + 1) + f];
-      float part = 0.f;
-      const bool valid = t < T;
-      for (int dd = 0; dd < 32; ++dd) {
-        const int d = grp * 32 + dd;
-        const float* w = p.loc_dense_w + d * LOC_F;
-        float loc = 0.f;
-#pragma unroll
-        for (int f = 0; f < LOC_F; ++f) loc += w[f] * cf[f];
-        const float pin = valid ? p.P[((size_t)b * ATT_DIM + d) * T + t] : 0.f;
-        part += p.v_w[d] * tanhf(s_q[d] + loc + pin);
-      }
-      s_part[grp * ATT_TT + tl] = part;
-    }
-    __syncthreads();
-    if (tid < ATT_TT && t0 + tid < T) {
-      const float e = s_part[tid] + s_part[ATT_TT + tid] + s_part[2 * ATT_TT + tid] + s_part[3 * ATT_TT + tid] + vb;
-      s_e[t0 + tid] = (t0 + tid < len) ? e : -INFINITY;
-    }
-    __syncthreads();
-  }
-
-  // normalise over the encoder axis
-  if (p.norm == TTSX_NORM_SOFTMAX) {
-    float m = -INFINITY;
-    for (int t = tid; t < T; t += ATT_THREADS) m = fmaxf(m, s_e[t]);
-    m = block_reduce_max(m, s_red, tid);
-    float sum = 0.f;
-    for (int t = tid; t < T; t += ATT_THREADS) {
-      const float e = expf(s_e[t] - m);
-      s_e[t] = e;
-      sum += e;
-    }
-    sum = block_reduce_sum(sum, s_red, tid);
-    for (int t = tid; t < T; t += ATT_THREADS) s_e[t] = s_e[t] / sum;
-  } else {
-    float sum = 0.f;
-    for (int t = tid; t < T; t += ATT_THREADS) {
-      const float s = sigmoidf_(s_e[t]);
-      s_e[t] = s;
-      sum += s;
-    }
-    sum = block_reduce_sum(sum, s_red, tid);
-    for (int t = tid; t < T; t += ATT_THREADS) s_e[t] = s_e[t] / sum;
+    s_cf[tp * 2][f] = acc0;
+    s_cf[tp * 2 + 1][f] = acc1;
   }
   __syncthreads();
-
-  const int row = p.ctrl->out_base + p.step_in_chunk;
-  for (int t = tid; t < T; t += ATT_THREADS) {
-    const float a = s_e[t];
-    p.a_prev[(size_t)b * T + t] = a;
-    p.a_cum[(size_t)b * T + t] = s_cum[t + ATT_PAD] + a;
-    p.align_out[((size_t)b * p.align_rows + row) * T + t] = a;
-  }
-  // context = a . enc : thread c owns column c
   {
-    const float* e = p.enc + (size_t)b * T * ENC_DIM + tid;
-    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
-    int t = 0;
-    for (; t + 4 <= len; t += 4) {
-      acc0 += s_e[t] * e[(size_t)t * ENC_DIM];
-      acc1 += s_e[t + 1] * e[(size_t)(t + 1) * ENC_DIM];
-      acc2 += s_e[t + 2] * e[(size_t)(t + 2) * ENC_DIM];
-      acc3 += s_e[t + 3] * e[(size_t)(t + 3) * ENC_DIM];
+    const int d = tid & 127, tg = tid >> 7;  // tg 0..3 -> positions tg*8 .. tg*8+7
+    float wd[LOC_F];
+    const float4* wsrc = reinterpret_cast<const float4*>(p.loc_dense_w + d * LOC_F);
+#pragma unroll
+    for (int i = 0; i < LOC_F / 4; ++i) {
+      const float4 t4 = wsrc[i];
+      wd[4 * i] = t4.x, wd[4 * i + 1] = t4.y, wd[4 * i + 2] = t4.z, wd[4 * i + 3] = t4.w;
     }
-    for (; t < len; ++t) acc0 += s_e[t] * e[(size_t)t * ENC_DIM];
-    p.ctx[qidx(tid, b, p.Bpad)] = (acc0 + acc1) + (acc2 + acc3);
+    const float qd = s_q[d], vd = p.v_w[d];
+    float pin[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int t = t0 + tg * 8 + i;
+      pin[i] = t < T ? p.P[((size_t)b * T + t) * ATT_DIM + d] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int tl = tg * 8 + i;
+      const float4* cf4 = reinterpret_cast<const float4*>(&s_cf[tl][0]);
+      float loc = 0.f;
+#pragma unroll
+      for (int k = 0; k < LOC_F / 4; ++k) {
+        const float4 c4 = cf4[k];
+        loc += wd[4 * k] * c4.x + wd[4 * k + 1] * c4.y + wd[4 * k + 2] * c4.z + wd[4 * k + 3] * c4.w;
+      }
+      float e = vd * tanhf(qd + loc + pin[i]);
+      e = wave_sum(e);
+      if ((tid & 63) == 0) s_part[(tid >> 6) & 1][tl] = e;
+    }
+  }
+  __syncthreads();
+  if (tid < EN_TT && t0 + tid < T) p.energies[(size_t)b * T + t0 + tid] = s_part[0][tid] + s_part[1][tid] + p.v_b[0];
+}
+
+// normalisation over the encoder axis (every workgroup of an utterance repeats it: T exps) and a
+// slice of CW context columns: ctx[c] = sum_t a[t] enc[t][c].  Workgroup x == 0 also writes the
+// alignment outputs and the location-attention state.
+template <int CW>
+__global__ __launch_bounds__(256) void context_kernel(AttnP p) {
+  RunCtx* cx = p.ctx;
+  if (cx->all_done) return;
+  const int T = cx->T, b = blockIdx.y, tid = threadIdx.x;
+  const int len = cx->enc_len ? cx->enc_len[b] : T;
+  extern __shared__ float s_dyn[];
+  float* s_al = s_dyn;  // [T]
+  __shared__ float s_red[4];
+  __shared__ float4 s_acc[256];
+
+  const bool softmax = p.norm == TTSX_NORM_SOFTMAX;
+  float m = -INFINITY;
+  if (softmax) {
+    for (int t = tid; t < len; t += 256) m = fmaxf(m, p.energies[(size_t)b * T + t]);
+    m = wave_max(m);
+    if ((tid & 63) == 0) s_red[tid >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+    __syncthreads();
+  }
+  float sum = 0.f;
+  for (int t = tid; t < T; t += 256) {
+    float v = 0.f;
+    if (t < len) {
+      const float e = p.energies[(size_t)b * T + t];
+      v = softmax ? expf(e - m) : sigmoidf_(e);
+    }
+    s_al[t] = v;
+    sum += v;
+  }
+  sum = wave_sum(sum);
+  if ((tid & 63) == 0) s_red[tid >> 6] = sum;
+  __syncthreads();
+  sum = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+  for (int t = tid; t < T; t += 256) s_al[t] = s_al[t] / sum;
+  __syncthreads();
+
+  if (blockIdx.x == 0) {
+    const int row = cx->out_base + p.step_in_chunk;
+    for (int t = tid; t < T; t += 256) {
+      const float a = s_al[t];
+      p.a_prev[(size_t)b * T + t] = a;
+      p.a_cum[(size_t)b * T + t] += a;
+      cx->align[((size_t)b * cx->align_rows + row) * T + t] = a;
+    }
+  }
+  // context slice: lane group = CW/4 float4 columns, row groups stride over t
+  constexpr int LPR = CW / 4, RG = 256 / LPR;
+  const int cl = tid % LPR, rg = tid / LPR;
+  const float4* e4 = reinterpret_cast<const float4*>(cx->enc + (size_t)b * T * ENC_DIM + blockIdx.x * CW) + cl;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  int t = rg;
+  for (; t + 3 * RG < len; t += 4 * RG) {
+    const float4 v0 = e4[(size_t)t * (ENC_DIM / 4)], v1 = e4[(size_t)(t + RG) * (ENC_DIM / 4)];
+    const float4 v2 = e4[(size_t)(t + 2 * RG) * (ENC_DIM / 4)], v3 = e4[(size_t)(t + 3 * RG) * (ENC_DIM / 4)];
+    const float a0 = s_al[t], a1 = s_al[t + RG], a2 = s_al[t + 2 * RG], a3 = s_al[t + 3 * RG];
+    acc.x += a0 * v0.x + a1 * v1.x + a2 * v2.x + a3 * v3.x;
+    acc.y += a0 * v0.y + a1 * v1.y + a2 * v2.y + a3 * v3.y;
+    acc.z += a0 * v0.z + a1 * v1.z + a2 * v2.z + a3 * v3.z;
+    acc.w += a0 * v0.w + a1 * v1.w + a2 * v2.w + a3 * v3.w;
+  }
+  for (; t < len; t += RG) {
+    const float4 v0 = e4[(size_t)t * (ENC_DIM / 4)];
+    const float a0 = s_al[t];
+    acc.x += a0 * v0.x, acc.y += a0 * v0.y, acc.z += a0 * v0.z, acc.w += a0 * v0.w;
+  }
+  s_acc[tid] = acc;
+  __syncthreads();
+  if (tid < LPR) {
+    float4 tot = s_acc[tid];
+    for (int g = 1; g < RG; ++g) {
+      const float4 v = s_acc[g * LPR + tid];
+      tot.x += v.x, tot.y += v.y, tot.z += v.z, tot.w += v.w;
+    }
+    const int quad = blockIdx.x * LPR + tid;
+    reinterpret_cast<float4*>(p.ctx_out)[(size_t)quad * p.Bpad + b] = tot;
   }
 }
 
-// processed_inputs, transposed: P[b][d][t] = sum_c enc[b][t][c] * w_in[d][c]
+// processed_inputs P[b][t][d] = sum_c enc[b][t][c] * w_in[d][c]
 // (OriginalAttention.preprocess_inputs, once per utterance).
 __global__ __launch_bounds__(256) void inputs_proj_kernel(float* __restrict__ P, const float* __restrict__ enc,
                                                           const float* __restrict__ w_in, int T) {
-  // block: 16 positions of one utterance; thread (tl = tid&15, dg = tid>>4) -> dims dg*8..+7
+  // block: 16 positions of one utterance; thread (d = tid&127, tg = tid>>7) -> positions tg*8 .. tg*8+7
   const int b = blockIdx.y, t0 = blockIdx.x * 16, tid = threadIdx.x;
-  __shared__ float s_enc[16][ENC_DIM + 1];
-  for (int i = tid; i < 16 * ENC_DIM; i += 256) {
-    const int tt = i / ENC_DIM, c = i % ENC_DIM;
-    s_enc[tt][c] = (t0 + tt < T) ? enc[((size_t)b * T + t0 + tt) * ENC_DIM + c] : 0.f;
+  __shared__ __attribute__((aligned(16))) float s_enc[16][ENC_DIM];
+  for (int i = tid; i < 16 * ENC_DIM / 4; i += 256) {
+    const int tt = i / (ENC_DIM / 4), c4 = i % (ENC_DIM / 4);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (t0 + tt < T) v = reinterpret_cast<const float4*>(enc + ((size_t)b * T + t0 + tt) * ENC_DIM)[c4];
+    reinterpret_cast<float4*>(&s_enc[tt][0])[c4] = v;
   }
   __syncthreads();
-  const int tl = tid & 15, dg = tid >> 4;
+  const int d = tid & 127, tg = tid >> 7;
   float acc[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) acc[i] = 0.f;
-  for (int c = 0; c < ENC_DIM; ++c) {
-    const float x = s_enc[tl][c];
+  const float4* w4 = reinterpret_cast<const float4*>(w_in + (size_t)d * ENC_DIM);
+  for (int c4 = 0; c4 < ENC_DIM / 4; ++c4) {
+    const float4 w = w4[c4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] += w_in[(dg * 8 + i) * ENC_DIM + c] * x;
+    for (int i = 0; i < 8; ++i) {
+      const float4 x = reinterpret_cast<const float4*>(&s_enc[tg * 8 + i][0])[c4];
+      acc[i] += w.x * x.x + w.y * x.y + w.z * x.z + w.w * x.w;
+    }
   }
-  if (t0 + tl < T) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) P[((size_t)b * ATT_DIM + dg * 8 + i) * T + t0 + tl] = acc[i];
+  for (int i = 0; i < 8; ++i) {
+    const int t = t0 + tg * 8 + i;
+    if (t < T) P[((size_t)b * T + t) * ATT_DIM + d] = acc[i];
   }
 }
 
 // ------------------------------------------------------------------ small utility kernels
-__global__ void ctrl_set_kernel(Ctrl* c, int base, int out_base, int reset_done) {
-  c->base = base;
-  c->out_base = out_base;
-  if (reset_done) c->all_done = 0, c->n_done = 0;
-}
-__global__ void ctrl_advance_kernel(Ctrl* c, int n) {
+__global__ void ctx_advance_kernel(RunCtx* c, int n) {
   if (c->all_done) return;
   c->base += n;
   c->out_base += n;
 }
-__global__ void finalize_steps_kernel(int32_t* n_steps, int B, const Ctrl* c, int steps_launched) {
+__global__ void finalize_steps_kernel(int32_t* n_steps, int B, int steps_launched) {
   int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b < B && n_steps[b] == 0) n_steps[b] = steps_launched;
+}
+// x1 for the first step: memory = 0, so layer 1 gives relu(bias)
+__global__ void init_x1_kernel(float* __restrict__ x1, const float* __restrict__ b1f, int Bpad) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < PRENET_DIM * Bpad) x1[qidx(i / Bpad, i % Bpad, Bpad)] = fmaxf(b1f[i / Bpad], 0.f);
 }
 // row-major [B][K] <-> quad-interleaved
 __global__ void to_quad_kernel(float* __restrict__ dst, const float* __restrict__ src, int B, int K, int Bpad) {
@@ -476,24 +609,30 @@ __global__ void from_quad_kernel(float* __restrict__ dst, const float* __restric
 // ------------------------------------------------------------------ host side
 struct ttsx_t2_decoder {
   int r_init, norm, odim;
+  // source-layout copies needed to compose rows for a new r
+  float *proj_w_src, *proj_b_src, *stop_w_src, *stop_b_src, *a1f, *b1f;
   // packed weights
-  float *w_lstm1, *b_lstm1, *w_lstm2, *b_lstm2, *w_query, *b_query, *w_proj, *b_proj;
-  float *pre_w1t, *pre_b1, *pre_w2t, *pre_b2;
-  float *stop_w, *stop_b, *inputs_w, *v_w, *v_b, *loc_conv_w, *loc_dense_w;
+  float *w_lstm1, *b_lstm1, *w_lstm2, *b_lstm2, *w_query, *b_query, *w_pre2, *b_pre2;
+  float *w_proj, *b_proj;  // mel rows + composed rows, valid for proj_r
+  int proj_r;
+  float *inputs_w, *v_w, *v_b, *loc_conv_w, *loc_dense_w;
   // per-run workspace
-  int B, T, Bpad, cap_B, cap_T;
-  const float* enc;
-  const int32_t* enc_len;
-  float *x2, *ctx, *h_a[2], *c_a, *h_d[2], *c_d, *q, *o, *a_prev, *a_cum, *P, *mem_tmp;
-  int32_t* n_steps_tmp;
-  float* stop_tmp;
-  Ctrl* ctrl;
-  int* host_flag;  // pinned
-  int steps_done;  // host mirror of ctrl.base
+  int B, T, Bpad, cap_B, cap_T, ws_gen;
+  float *x1, *x2, *ctx, *h_a[2], *c_a, *h_d[2], *c_d, *q, *o, *a_prev, *a_cum, *energies, *P;
+  RunCtx* rc;        // device
+  RunCtx* rc_host;   // pinned staging copy
+  int* host_flag;    // pinned
+  int steps_done;    // host mirror of rc.base
   bool begun;
+  // cached chunk graph
+  hipGraphExec_t graph;
+  hipStream_t cap_stream;  // capture-only stream: the caller's stream may be the legacy default stream
+  int g_B, g_T, g_r, g_gen, g_chunk;
 };
 
 namespace {
+
+constexpr int CHUNK = 32;
 
 template <typename T>
 int dev_alloc(T** p, size_t n) {
@@ -512,159 +651,227 @@ int pack_layer(float** wp, float** bp, const float* w1, int k1, const float* w2,
                const float* b2, int rows, int lstm_hidden, hipStream_t st) {
   const int KG = (k1 + k2) / 16, nrb = ceil_div(rows, 16);
   const size_t n = (size_t)nrb * KG * 256;
-  int rc = dev_alloc(wp, n);
-  if (rc) return rc;
-  rc = dev_alloc(bp, (size_t)nrb * 16);
-  if (rc) return rc;
-  pack_rows_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(*wp, w1, k1, w2, k2, rows, KG, lstm_hidden, nullptr);
+  if (!*wp) {
+    int rc = dev_alloc(wp, n);
+    if (rc) return rc;
+    rc = dev_alloc(bp, (size_t)nrb * 16);
+    if (rc) return rc;
+  }
+  pack_rows_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(*wp, w1, k1, w2, k2, rows, KG, lstm_hidden);
   TTSX_LAUNCH_CHECK();
   pack_bias_kernel<<<ceil_div(nrb * 16, 256), 256, 0, st>>>(*bp, b1, b2, rows, lstm_hidden);
   TTSX_LAUNCH_CHECK();
   return TTSX_OK;
 }
 
+void drop_graph(ttsx_t2_decoder* d) {
+  if (d->graph) (void)hipGraphExecDestroy(d->graph);
+  d->graph = nullptr;
+}
+
 void free_workspace(ttsx_t2_decoder* d) {
-  float** bufs[] = {&d->x2, &d->ctx, &d->h_a[0], &d->h_a[1], &d->c_a, &d->h_d[0], &d->h_d[1], &d->c_d,
-                    &d->q,  &d->o,   &d->a_prev, &d->a_cum,  &d->P,   &d->mem_tmp, &d->stop_tmp};
+  float** bufs[] = {&d->x1, &d->x2, &d->ctx, &d->h_a[0], &d->h_a[1], &d->c_a, &d->h_d[0], &d->h_d[1], &d->c_d,
+                    &d->q,  &d->o,  &d->a_prev, &d->a_cum, &d->energies, &d->P};
   for (float** b : bufs) {
     if (*b) (void)hipFree(*b);
     *b = nullptr;
   }
-  if (d->n_steps_tmp) (void)hipFree(d->n_steps_tmp);
-  d->n_steps_tmp = nullptr;
   d->cap_B = d->cap_T = 0;
+  drop_graph(d);
 }
 
+int proj_rows(const ttsx_t2_decoder* d) { return d->odim + 16 + PRENET_DIM; }
+
 int ensure_workspace(ttsx_t2_decoder* d, int B, int T) {
-  const int Bpad = B <= 64 ? round_up(B, 16) : round_up(B, 64);
-  if (d->cap_B >= Bpad && d->cap_T >= T) {
+  const int Bpad = B <= GEMV_MAX_B ? B : (B <= 64 ? round_up(B, 16) : round_up(B, 64));
+  if (d->cap_B == Bpad && d->cap_T >= T) {
     d->Bpad = Bpad;
     return TTSX_OK;
   }
   free_workspace(d);
-  const int cb = Bpad, ct = T;
+  const size_t cb = Bpad, ct = T;
   int rc = 0;
-  rc |= dev_alloc(&d->x2, (size_t)PRENET_DIM * cb);
-  rc |= dev_alloc(&d->ctx, (size_t)ENC_DIM * cb);
+  rc |= dev_alloc(&d->x1, PRENET_DIM * cb);
+  rc |= dev_alloc(&d->x2, PRENET_DIM * cb);
+  rc |= dev_alloc(&d->ctx, ENC_DIM * cb);
   for (int i = 0; i < 2; ++i) {
-    rc |= dev_alloc(&d->h_a[i], (size_t)QUERY_DIM * cb);
-    rc |= dev_alloc(&d->h_d[i], (size_t)DEC_DIM * cb);
+    rc |= dev_alloc(&d->h_a[i], QUERY_DIM * cb);
+    rc |= dev_alloc(&d->h_d[i], DEC_DIM * cb);
   }
-  rc |= dev_alloc(&d->c_a, (size_t)QUERY_DIM * cb);
-  rc |= dev_alloc(&d->c_d, (size_t)DEC_DIM * cb);
-  rc |= dev_alloc(&d->q, (size_t)ATT_DIM * cb);
-  rc |= dev_alloc(&d->o, (size_t)round_up(d->odim, 16) * cb);
-  rc |= dev_alloc(&d->a_prev, (size_t)cb * ct);
-  rc |= dev_alloc(&d->a_cum, (size_t)cb * ct);
-  rc |= dev_alloc(&d->P, (size_t)cb * ATT_DIM * ct);
-  rc |= dev_alloc(&d->mem_tmp, (size_t)cb * MEL_DIM);
-  rc |= dev_alloc(&d->stop_tmp, (size_t)cb);
-  rc |= dev_alloc(&d->n_steps_tmp, (size_t)cb);
+  rc |= dev_alloc(&d->c_a, QUERY_DIM * cb);
+  rc |= dev_alloc(&d->c_d, DEC_DIM * cb);
+  rc |= dev_alloc(&d->q, ATT_DIM * cb);
+  rc |= dev_alloc(&d->o, (size_t)round_up(proj_rows(d), 16) * cb);
+  rc |= dev_alloc(&d->a_prev, cb * ct);
+  rc |= dev_alloc(&d->a_cum, cb * ct);
+  rc |= dev_alloc(&d->energies, cb * ct);
+  rc |= dev_alloc(&d->P, cb * ATT_DIM * ct);
   if (rc) return TTSX_ERR_HIP;
-  d->cap_B = cb, d->cap_T = ct, d->Bpad = Bpad;
+  d->cap_B = Bpad, d->cap_T = T, d->Bpad = Bpad;
+  d->ws_gen += 1;
   return TTSX_OK;
 }
 
-size_t attn_smem_bytes(int T) {
-  return sizeof(float) * (size_t)(2 * (T + 2 * ATT_PAD) + T + ATT_TT * (LOC_F + 1) + 4 * ATT_TT + ATT_DIM + 8);
+// (Re)build the projection rows for reduction factor r.
+int ensure_proj(ttsx_t2_decoder* d, int r, hipStream_t st) {
+  if (d->proj_r == r) return TTSX_OK;
+  const int K = DEC_DIM + ENC_DIM, ext_rows = 16 + PRENET_DIM;
+  float *ext_w = nullptr, *ext_b = nullptr, *all_w = nullptr, *all_b = nullptr;
+  if (dev_alloc(&ext_w, (size_t)ext_rows * K) || dev_alloc(&ext_b, ext_rows)) return TTSX_ERR_HIP;
+  compose_proj_ext_kernel<<<ext_rows, 256, 0, st>>>(ext_w, ext_b, d->proj_w_src, d->proj_b_src, d->stop_w_src,
+                                                   d->stop_b_src, d->a1f, d->b1f, d->odim, r);
+  TTSX_LAUNCH_CHECK();
+  const int rows = proj_rows(d);
+  if (dev_alloc(&all_w, (size_t)rows * K) || dev_alloc(&all_b, rows)) return TTSX_ERR_HIP;
+  TTSX_HIP(hipMemcpyAsync(all_w, d->proj_w_src, sizeof(float) * (size_t)d->odim * K, hipMemcpyDeviceToDevice, st));
+  TTSX_HIP(hipMemcpyAsync(all_w + (size_t)d->odim * K, ext_w, sizeof(float) * (size_t)ext_rows * K,
+                          hipMemcpyDeviceToDevice, st));
+  TTSX_HIP(hipMemcpyAsync(all_b, d->proj_b_src, sizeof(float) * d->odim, hipMemcpyDeviceToDevice, st));
+  TTSX_HIP(hipMemcpyAsync(all_b + d->odim, ext_b, sizeof(float) * ext_rows, hipMemcpyDeviceToDevice, st));
+  int rc = pack_layer(&d->w_proj, &d->b_proj, all_w, K, nullptr, 0, all_b, nullptr, rows, 0, st);
+  TTSX_HIP(hipStreamSynchronize(st));
+  (void)hipFree(ext_w), (void)hipFree(ext_b), (void)hipFree(all_w), (void)hipFree(all_b);
+  if (rc) return rc;
+  d->proj_r = r;
+  drop_graph(d);
+  return TTSX_OK;
 }
 
 template <int MODE>
-int launch_gemm(const GemmP& p, int nrb, hipStream_t st) {
-  const int nt_total = p.Bpad / 16;
-  if (nt_total <= 4) {
-    dim3 grid(nrb, 1);
-    switch (nt_total) {
-      case 1: rowblock_gemm_kernel<1, MODE><<<grid, GEMM_THREADS, 0, st>>>(p); break;
-      case 2: rowblock_gemm_kernel<2, MODE><<<grid, GEMM_THREADS, 0, st>>>(p); break;
-      case 3: rowblock_gemm_kernel<3, MODE><<<grid, GEMM_THREADS, 0, st>>>(p); break;
-      default: rowblock_gemm_kernel<4, MODE><<<grid, GEMM_THREADS, 0, st>>>(p); break;
+int launch_gemm(const ttsx_t2_decoder* d, const GemmP& p, int nrb, bool split_n, hipStream_t st) {
+  const int B = d->B;
+  if (B <= GEMV_MAX_B) {
+    dim3 grid(nrb);
+#define TTSX_GEMV(NB, KGW) rowblock_gemv_kernel<NB, KGW, MODE><<<grid, GEMM_THREADS, 0, st>>>(p)
+#define TTSX_GEMV_NB(KGW)       \
+  switch (B) {                  \
+    case 1: TTSX_GEMV(1, KGW); break; \
+    default: TTSX_GEMV(2, KGW); break; \
+  }
+    switch (p.KG) {
+      case 16: TTSX_GEMV_NB(2); break;    // prenet layer 2 (K=256)
+      case 64: TTSX_GEMV_NB(8); break;    // query (K=1024)
+      case 96: TTSX_GEMV_NB(12); break;   // projection (K=1536)
+      case 112: TTSX_GEMV_NB(14); break;  // attention LSTM (K=1792)
+      case 160: TTSX_GEMV_NB(20); break;  // decoder LSTM (K=2560)
+      default:
+        ttsx_set_error("launch_gemm: no GEMV instance for KG=%d", p.KG);
+        return TTSX_ERR_ARG;
     }
+#undef TTSX_GEMV_NB
+#undef TTSX_GEMV
   } else {
-    dim3 grid(nrb, p.Bpad / 64);
-    rowblock_gemm_kernel<4, MODE><<<grid, GEMM_THREADS, 0, st>>>(p);
+    const int nt_total = p.Bpad / 16;
+    if (split_n || nt_total > 4) {
+      // small-row GEMMs: one column tile per workgroup for parallelism; or batch > 64
+      if (split_n) {
+        dim3 grid(nrb, nt_total);
+        rowblock_gemm_kernel<1, MODE><<<grid, GEMM_THREADS, 0, st>>>(p);
+      } else {
+        dim3 grid(nrb, p.Bpad / 64);
+        rowblock_gemm_kernel<4, MODE><<<grid, GEMM_THREADS, 0, st>>>(p);
+      }
+    } else {
+      dim3 grid(nrb, 1);
+      switch (nt_total) {
+        case 1: rowblock_gemm_kernel<1, MODE><<<grid, GEMM_THREADS, 0, st>>>(p); break;
+        case 2: rowblock_gemm_kernel<2, MODE><<<grid, GEMM_THREADS, 0, st>>>(p); break;
+        case 3: rowblock_gemm_kernel<3, MODE><<<grid, GEMM_THREADS, 0, st>>>(p); break;
+        default: rowblock_gemm_kernel<4, MODE><<<grid, GEMM_THREADS, 0, st>>>(p); break;
+      }
+    }
   }
   TTSX_LAUNCH_CHECK();
   return TTSX_OK;
 }
 
-struct StepOut {
-  float* mel;
-  int mel_rows;
-  float* align;
-  int align_rows;
-  float* stop;
-  int stop_rows;
-  int32_t* n_steps;
-};
-
-// Enqueue one decoder step.  `i` is the step's index inside the current chunk.
-int enqueue_step(ttsx_t2_decoder* d, int i, int r, const StepOut& o, const float* mem_override, bool stop_prev,
-                 bool free_running, float thr, hipStream_t st) {
-  const int Bpad = d->Bpad, B = d->B;
-  PrenetP pp{};
-  pp.w1t = d->pre_w1t, pp.b1 = d->pre_b1, pp.w2t = d->pre_w2t, pp.b2 = d->pre_b2;
-  pp.stop_w = d->stop_w, pp.stop_b = d->stop_b;
-  pp.h_d[0] = d->h_d[0], pp.h_d[1] = d->h_d[1], pp.o = d->o, pp.mem_override = mem_override;
-  pp.x2 = d->x2, pp.stop_out = o.stop, pp.n_steps = o.n_steps, pp.ctrl = d->ctrl;
-  pp.step_in_chunk = i, pp.Bpad = Bpad, pp.B = B, pp.r = r, pp.r_init = d->r_init, pp.stop_rows = o.stop_rows;
-  pp.do_stop = stop_prev, pp.do_prenet = 1, pp.free_running = free_running, pp.threshold = thr;
-  prenet_stop_kernel<<<B, 256, 0, st>>>(pp);
-  TTSX_LAUNCH_CHECK();
-
+// Enqueue one decoder step; `i` is the step's index inside the current chunk.
+int enqueue_step(ttsx_t2_decoder* d, int i, hipStream_t st) {
+  const int Bpad = d->Bpad, B = d->B, T = d->T;
   GemmP g{};
-  g.Bpad = Bpad, g.B = B, g.ctrl = d->ctrl, g.step_in_chunk = i, g.r = r;
+  g.Bpad = Bpad, g.ctx = d->rc, g.step_in_chunk = i;
+  int rc;
+  // prenet layer 2: x2 = relu(A2f x1 + b2f)
+  g.Wp = d->w_pre2, g.bias = d->b_pre2, g.nseg = 1, g.KG = PRENET_DIM / 16;
+  g.seg[0] = Seg{{d->x1, nullptr}, 0, PRENET_DIM / 16};
+  g.out[0] = d->x2, g.relu = 1;
+  if ((rc = launch_gemm<MODE_LINEAR>(d, g, PRENET_DIM / 16, true, st))) return rc;
   // attention LSTM: [x2; ctx; h_a]
   g.Wp = d->w_lstm1, g.bias = d->b_lstm1, g.nseg = 3, g.KG = (PRENET_DIM + ENC_DIM + QUERY_DIM) / 16;
   g.seg[0] = Seg{{d->x2, nullptr}, 0, PRENET_DIM / 16};
   g.seg[1] = Seg{{d->ctx, nullptr}, 0, ENC_DIM / 16};
   g.seg[2] = Seg{{d->h_a[0], d->h_a[1]}, 1, QUERY_DIM / 16};
-  g.out[0] = d->h_a[0], g.out[1] = d->h_a[1], g.c = d->c_a, g.rows = 4 * QUERY_DIM;
-  int rc = launch_gemm<MODE_LSTM>(g, QUERY_DIM / 4, st);
-  if (rc) return rc;
+  g.out[0] = d->h_a[0], g.out[1] = d->h_a[1], g.c = d->c_a, g.relu = 0;
+  if ((rc = launch_gemm<MODE_LSTM>(d, g, QUERY_DIM / 4, false, st))) return rc;
   // query projection
   g.Wp = d->w_query, g.bias = d->b_query, g.nseg = 1, g.KG = QUERY_DIM / 16;
   g.seg[0] = Seg{{d->h_a[0], d->h_a[1]}, 2, QUERY_DIM / 16};
-  g.out[0] = d->q, g.out[1] = nullptr, g.c = nullptr, g.rows = ATT_DIM;
-  rc = launch_gemm<MODE_LINEAR>(g, ATT_DIM / 16, st);
-  if (rc) return rc;
+  g.out[0] = d->q, g.out[1] = nullptr, g.c = nullptr;
+  if ((rc = launch_gemm<MODE_LINEAR>(d, g, ATT_DIM / 16, true, st))) return rc;
   // attention
   AttnP ap{};
-  ap.q = d->q, ap.P = d->P, ap.enc = d->enc, ap.enc_len = d->enc_len;
+  ap.q = d->q, ap.P = d->P;
   ap.loc_conv_w = d->loc_conv_w, ap.loc_dense_w = d->loc_dense_w, ap.v_w = d->v_w, ap.v_b = d->v_b;
-  ap.a_prev = d->a_prev, ap.a_cum = d->a_cum, ap.ctx = d->ctx, ap.align_out = o.align;
-  ap.ctrl = d->ctrl, ap.step_in_chunk = i, ap.Bpad = Bpad, ap.T = d->T, ap.align_rows = o.align_rows;
-  ap.norm = d->norm;
-  attention_kernel<<<B, ATT_THREADS, attn_smem_bytes(d->T), st>>>(ap);
+  ap.a_prev = d->a_prev, ap.a_cum = d->a_cum, ap.energies = d->energies, ap.ctx_out = d->ctx;
+  ap.ctx = d->rc, ap.step_in_chunk = i, ap.Bpad = Bpad, ap.norm = d->norm;
+  energy_kernel<<<dim3(ceil_div(T, EN_TT), B), EN_THREADS, 0, st>>>(ap);
+  TTSX_LAUNCH_CHECK();
+  if (B >= 16) context_kernel<128><<<dim3(ENC_DIM / 128, B), 256, sizeof(float) * T, st>>>(ap);
+  else context_kernel<32><<<dim3(ENC_DIM / 32, B), 256, sizeof(float) * T, st>>>(ap);
   TTSX_LAUNCH_CHECK();
   // decoder LSTM: [h_a(new); ctx; h_d]
   g.Wp = d->w_lstm2, g.bias = d->b_lstm2, g.nseg = 3, g.KG = (QUERY_DIM + ENC_DIM + DEC_DIM) / 16;
   g.seg[0] = Seg{{d->h_a[0], d->h_a[1]}, 2, QUERY_DIM / 16};
   g.seg[1] = Seg{{d->ctx, nullptr}, 0, ENC_DIM / 16};
   g.seg[2] = Seg{{d->h_d[0], d->h_d[1]}, 1, DEC_DIM / 16};
-  g.out[0] = d->h_d[0], g.out[1] = d->h_d[1], g.c = d->c_d, g.rows = 4 * DEC_DIM;
-  rc = launch_gemm<MODE_LSTM>(g, DEC_DIM / 4, st);
-  if (rc) return rc;
-  // mel projection: [h_d(new); ctx]
+  g.out[0] = d->h_d[0], g.out[1] = d->h_d[1], g.c = d->c_d;
+  if ((rc = launch_gemm<MODE_LSTM>(d, g, DEC_DIM / 4, false, st))) return rc;
+  // projection: mel rows, stop row, next step's prenet layer-1 rows
   g.Wp = d->w_proj, g.bias = d->b_proj, g.nseg = 2, g.KG = (DEC_DIM + ENC_DIM) / 16;
   g.seg[0] = Seg{{d->h_d[0], d->h_d[1]}, 2, DEC_DIM / 16};
   g.seg[1] = Seg{{d->ctx, nullptr}, 0, ENC_DIM / 16};
-  g.out[0] = d->o, g.out[1] = nullptr, g.c = nullptr, g.rows = d->odim;
-  g.mel = o.mel, g.mel_rows = o.mel_rows;
-  rc = launch_gemm<MODE_PROJ>(g, ceil_div(d->odim, 16), st);
-  return rc;
+  g.out[0] = d->o, g.out[1] = nullptr, g.c = nullptr, g.x1 = d->x1, g.o_quads = d->odim / 4;
+  return launch_gemm<MODE_PROJ>(d, g, ceil_div(proj_rows(d), 16), true, st);
 }
 
-// stop token of the chunk's last step (index i inside the chunk)
-int enqueue_stop_only(ttsx_t2_decoder* d, int i, int r, const StepOut& o, bool free_running, float thr,
-                      hipStream_t st) {
-  PrenetP pp{};
-  pp.stop_w = d->stop_w, pp.stop_b = d->stop_b;
-  pp.h_d[0] = d->h_d[0], pp.h_d[1] = d->h_d[1], pp.o = d->o;
-  pp.stop_out = o.stop, pp.n_steps = o.n_steps, pp.ctrl = d->ctrl;
-  pp.step_in_chunk = i + 1, pp.Bpad = d->Bpad, pp.B = d->B, pp.r = r, pp.r_init = d->r_init;
-  pp.stop_rows = o.stop_rows, pp.do_stop = 1, pp.do_prenet = 0, pp.free_running = free_running, pp.threshold = thr;
-  prenet_stop_kernel<<<d->B, 256, 0, st>>>(pp);
+int push_ctx(ttsx_t2_decoder* d, hipStream_t st) {
+  TTSX_HIP(hipMemcpyAsync(d->rc, d->rc_host, sizeof(RunCtx), hipMemcpyHostToDevice, st));
+  // the pinned staging copy is reused by the next call: make sure this one has been read
+  TTSX_HIP(hipStreamSynchronize(st));
+  return TTSX_OK;
+}
+
+// Launch `n` steps as one graph (captured once per (B, T, r, workspace) and chunk size).
+int launch_chunk(ttsx_t2_decoder* d, int n, hipStream_t st) {
+  const bool cached = d->graph && d->g_B == d->B && d->g_T == d->T && d->g_r == d->rc_host->r &&
+                      d->g_gen == d->ws_gen && d->g_chunk == n;
+  if (!cached && n == CHUNK) {
+    drop_graph(d);
+    hipGraph_t graph = nullptr;
+    hipStream_t cs = d->cap_stream;
+    TTSX_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
+    int rc = TTSX_OK;
+    for (int i = 0; i < n && !rc; ++i) rc = enqueue_step(d, i, cs);
+    if (!rc) ctx_advance_kernel<<<1, 1, 0, cs>>>(d->rc, n);
+    hipError_t e = hipStreamEndCapture(cs, &graph);
+    if (rc) {
+      if (graph) (void)hipGraphDestroy(graph);
+      return rc;
+    }
+    TTSX_HIP(e);
+    TTSX_HIP(hipGraphInstantiate(&d->graph, graph, nullptr, nullptr, 0));
+    (void)hipGraphDestroy(graph);
+    d->g_B = d->B, d->g_T = d->T, d->g_r = d->rc_host->r, d->g_gen = d->ws_gen, d->g_chunk = n;
+  }
+  if (n == CHUNK) {
+    TTSX_HIP(hipGraphLaunch(d->graph, st));
+    return TTSX_OK;
+  }
+  for (int i = 0; i < n; ++i) {
+    int rc = enqueue_step(d, i, st);
+    if (rc) return rc;
+  }
+  ctx_advance_kernel<<<1, 1, 0, st>>>(d->rc, n);
   TTSX_LAUNCH_CHECK();
   return TTSX_OK;
 }
@@ -687,31 +894,41 @@ extern "C" int ttsx_t2_decoder_create(const ttsx_t2_decoder_weights* w, int r_in
   rc |= pack_layer(&d->w_lstm2, &d->b_lstm2, w->dec_rnn_w_ih, QUERY_DIM + ENC_DIM, w->dec_rnn_w_hh, DEC_DIM,
                    w->dec_rnn_b_ih, w->dec_rnn_b_hh, 4 * DEC_DIM, DEC_DIM, st);
   rc |= pack_layer(&d->w_query, &d->b_query, w->query_w, QUERY_DIM, nullptr, 0, nullptr, nullptr, ATT_DIM, 0, st);
-  rc |= pack_layer(&d->w_proj, &d->b_proj, w->proj_w, DEC_DIM + ENC_DIM, nullptr, 0, w->proj_b, nullptr, d->odim, 0,
-                   st);
   if (rc) return TTSX_ERR_HIP;
-  const int pin[2] = {MEL_DIM, PRENET_DIM};
-  float** wt[2] = {&d->pre_w1t, &d->pre_w2t};
-  float** bt[2] = {&d->pre_b1, &d->pre_b2};
-  for (int i = 0; i < 2; ++i) {
-    if (dev_alloc(wt[i], (size_t)pin[i] * PRENET_DIM) || dev_alloc(bt[i], PRENET_DIM)) return TTSX_ERR_HIP;
-    pack_prenet_kernel<<<ceil_div(pin[i] * PRENET_DIM, 256), 256, 0, st>>>(
-        *wt[i], *bt[i], w->prenet_w[i], w->prenet_bn_weight[i], w->prenet_bn_bias[i], w->prenet_bn_mean[i],
-        w->prenet_bn_var[i], PRENET_DIM, pin[i]);
-    TTSX_LAUNCH_CHECK();
-  }
-  rc |= copy_dev(&d->stop_w, w->stop_w, DEC_DIM + d->odim, st);
-  rc |= copy_dev(&d->stop_b, w->stop_b, 1, st);
+  // prenet: fold BatchNorm, keep layer 1 in source layout for the composed projection rows
+  float *a2f = nullptr, *b2f = nullptr;
+  if (dev_alloc(&d->a1f, PRENET_DIM * MEL_DIM) || dev_alloc(&d->b1f, PRENET_DIM) ||
+      dev_alloc(&a2f, PRENET_DIM * PRENET_DIM) || dev_alloc(&b2f, PRENET_DIM))
+    return TTSX_ERR_HIP;
+  fold_prenet_kernel<<<ceil_div(PRENET_DIM * MEL_DIM, 256), 256, 0, st>>>(
+      d->a1f, d->b1f, w->prenet_w[0], w->prenet_bn_weight[0], w->prenet_bn_bias[0], w->prenet_bn_mean[0],
+      w->prenet_bn_var[0], PRENET_DIM, MEL_DIM);
+  TTSX_LAUNCH_CHECK();
+  fold_prenet_kernel<<<ceil_div(PRENET_DIM * PRENET_DIM, 256), 256, 0, st>>>(
+      a2f, b2f, w->prenet_w[1], w->prenet_bn_weight[1], w->prenet_bn_bias[1], w->prenet_bn_mean[1],
+      w->prenet_bn_var[1], PRENET_DIM, PRENET_DIM);
+  TTSX_LAUNCH_CHECK();
+  rc |= pack_layer(&d->w_pre2, &d->b_pre2, a2f, PRENET_DIM, nullptr, 0, b2f, nullptr, PRENET_DIM, 0, st);
+  rc |= copy_dev(&d->proj_w_src, w->proj_w, (size_t)d->odim * (DEC_DIM + ENC_DIM), st);
+  rc |= copy_dev(&d->proj_b_src, w->proj_b, d->odim, st);
+  rc |= copy_dev(&d->stop_w_src, w->stop_w, DEC_DIM + d->odim, st);
+  rc |= copy_dev(&d->stop_b_src, w->stop_b, 1, st);
   rc |= copy_dev(&d->inputs_w, w->inputs_w, ATT_DIM * ENC_DIM, st);
   rc |= copy_dev(&d->v_w, w->v_w, ATT_DIM, st);
   rc |= copy_dev(&d->v_b, w->v_b, 1, st);
   rc |= copy_dev(&d->loc_conv_w, w->loc_conv_w, LOC_F * 2 * LOC_K, st);
   rc |= copy_dev(&d->loc_dense_w, w->loc_dense_w, ATT_DIM * LOC_F, st);
   if (rc) return TTSX_ERR_HIP;
-  TTSX_HIP(hipMalloc(reinterpret_cast<void**>(&d->ctrl), sizeof(Ctrl)));
-  TTSX_HIP(hipMemsetAsync(d->ctrl, 0, sizeof(Ctrl), st));
+  TTSX_HIP(hipMalloc(reinterpret_cast<void**>(&d->rc), sizeof(RunCtx)));
+  TTSX_HIP(hipMemsetAsync(d->rc, 0, sizeof(RunCtx), st));
+  TTSX_HIP(hipHostMalloc(reinterpret_cast<void**>(&d->rc_host), sizeof(RunCtx), hipHostMallocDefault));
   TTSX_HIP(hipHostMalloc(reinterpret_cast<void**>(&d->host_flag), 4 * sizeof(int), hipHostMallocDefault));
+  memset(d->rc_host, 0, sizeof(RunCtx));
+  TTSX_HIP(hipStreamCreateWithFlags(&d->cap_stream, hipStreamNonBlocking));
   TTSX_HIP(hipStreamSynchronize(st));
+  (void)hipFree(a2f), (void)hipFree(b2f);
+  rc = ensure_proj(d, r_init, st);
+  if (rc) return rc;
   *out = d;
   return TTSX_OK;
 }
@@ -719,12 +936,14 @@ extern "C" int ttsx_t2_decoder_create(const ttsx_t2_decoder_weights* w, int r_in
 extern "C" int ttsx_t2_decoder_destroy(ttsx_t2_decoder* d) {
   if (!d) return TTSX_OK;
   free_workspace(d);
-  float* bufs[] = {d->w_lstm1, d->b_lstm1, d->w_lstm2, d->b_lstm2, d->w_query, d->b_query, d->w_proj,
-                   d->b_proj,  d->pre_w1t, d->pre_b1,  d->pre_w2t, d->pre_b2,  d->stop_w,  d->stop_b,
-                   d->inputs_w, d->v_w,    d->v_b,     d->loc_conv_w, d->loc_dense_w};
+  float* bufs[] = {d->w_lstm1, d->b_lstm1, d->w_lstm2, d->b_lstm2, d->w_query, d->b_query,
+                   d->w_pre2,  d->b_pre2,  d->w_proj,  d->b_proj,  d->proj_w_src, d->proj_b_src, d->stop_w_src,
+                   d->stop_b_src, d->a1f, d->b1f, d->inputs_w, d->v_w, d->v_b, d->loc_conv_w, d->loc_dense_w};
   for (float* b : bufs)
     if (b) (void)hipFree(b);
-  if (d->ctrl) (void)hipFree(d->ctrl);
+  if (d->cap_stream) (void)hipStreamDestroy(d->cap_stream);
+  if (d->rc) (void)hipFree(d->rc);
+  if (d->rc_host) (void)hipHostFree(d->rc_host);
   if (d->host_flag) (void)hipHostFree(d->host_flag);
   delete d;
   return TTSX_OK;
@@ -734,12 +953,12 @@ extern "C" int ttsx_t2_decoder_begin(ttsx_t2_decoder* d, const float* enc, const
                                      void* stream) {
   TTSX_ARG(d && enc, "ttsx_t2_decoder_begin: null argument");
   TTSX_ARG(B >= 1 && B <= 4096 && T >= 1, "ttsx_t2_decoder_begin: bad shape B=%d T=%d", B, T);
-  TTSX_ARG(attn_smem_bytes(T) <= 160 * 1024, "ttsx_t2_decoder_begin: encoder length %d exceeds the LDS budget", T);
+  TTSX_ARG(T <= 16000, "ttsx_t2_decoder_begin: encoder length %d exceeds the LDS budget of the context kernel", T);
   hipStream_t st = static_cast<hipStream_t>(stream);
   int rc = ensure_workspace(d, B, T);
   if (rc) return rc;
-  d->B = B, d->T = T, d->enc = enc, d->enc_len = enc_len;
-  const int cb = d->Bpad;
+  d->B = B, d->T = T;
+  const size_t cb = d->Bpad;
   TTSX_HIP(hipMemsetAsync(d->x2, 0, sizeof(float) * PRENET_DIM * cb, st));
   TTSX_HIP(hipMemsetAsync(d->ctx, 0, sizeof(float) * ENC_DIM * cb, st));
   for (int i = 0; i < 2; ++i) {
@@ -749,19 +968,26 @@ extern "C" int ttsx_t2_decoder_begin(ttsx_t2_decoder* d, const float* enc, const
   TTSX_HIP(hipMemsetAsync(d->c_a, 0, sizeof(float) * QUERY_DIM * cb, st));
   TTSX_HIP(hipMemsetAsync(d->c_d, 0, sizeof(float) * DEC_DIM * cb, st));
   TTSX_HIP(hipMemsetAsync(d->q, 0, sizeof(float) * ATT_DIM * cb, st));
-  TTSX_HIP(hipMemsetAsync(d->o, 0, sizeof(float) * round_up(d->odim, 16) * cb, st));
+  TTSX_HIP(hipMemsetAsync(d->o, 0, sizeof(float) * (size_t)round_up(proj_rows(d), 16) * cb, st));
   TTSX_HIP(hipMemsetAsync(d->a_prev, 0, sizeof(float) * (size_t)B * T, st));
   TTSX_HIP(hipMemsetAsync(d->a_cum, 0, sizeof(float) * (size_t)B * T, st));
-  if (attn_smem_bytes(T) > 64 * 1024)
-    TTSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_smem_bytes(T)));
+  init_x1_kernel<<<ceil_div(PRENET_DIM * (int)cb, 256), 256, 0, st>>>(d->x1, d->b1f, (int)cb);
+  TTSX_LAUNCH_CHECK();
+  if (sizeof(float) * T > 48 * 1024) {
+    TTSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(context_kernel<32>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * T)));
+    TTSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(context_kernel<128>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * T)));
+  }
   inputs_proj_kernel<<<dim3(ceil_div(T, 16), B), 256, 0, st>>>(d->P, enc, d->inputs_w, T);
   TTSX_LAUNCH_CHECK();
-  ctrl_set_kernel<<<1, 1, 0, st>>>(d->ctrl, 0, 0, 1);
-  TTSX_LAUNCH_CHECK();
+  RunCtx* h = d->rc_host;
+  memset(h, 0, sizeof(*h));
+  h->B = B, h->T = T, h->r = d->proj_r, h->threshold = 2.f;
+  h->enc = enc, h->enc_len = enc_len;
   d->steps_done = 0;
   d->begun = true;
-  return TTSX_OK;
+  return push_ctx(d, st);
 }
 
 extern "C" int ttsx_t2_decoder_load_state(ttsx_t2_decoder* d, const float* h_a, const float* c_a, const float* h_d,
@@ -811,6 +1037,20 @@ extern "C" int ttsx_t2_decoder_read_state(ttsx_t2_decoder* d, float* h_a, float*
   return TTSX_OK;
 }
 
+namespace {
+// prenet layer 1 on an explicit memory frame (row-major [B,80]), any batch size: tiny, one thread per output
+__global__ void prenet1_explicit_kernel(float* __restrict__ x1, const float* __restrict__ mem,
+                                        const float* __restrict__ a1f, const float* __restrict__ b1f, int B,
+                                        int Bpad) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * PRENET_DIM) return;
+  const int b = i / PRENET_DIM, n = i % PRENET_DIM;
+  float acc = b1f[n];
+  for (int k = 0; k < MEL_DIM; ++k) acc += a1f[n * MEL_DIM + k] * mem[b * MEL_DIM + k];
+  x1[qidx(n, b, Bpad)] = fmaxf(acc, 0.f);
+}
+}  // namespace
+
 extern "C" int ttsx_t2_decoder_step(ttsx_t2_decoder* d, const float* memory, int r, float* frames, float* align,
                                     float* stop, void* stream) {
   TTSX_ARG(d && memory && frames && align && stop, "ttsx_t2_decoder_step: null argument");
@@ -820,13 +1060,21 @@ extern "C" int ttsx_t2_decoder_step(ttsx_t2_decoder* d, const float* memory, int
     return TTSX_ERR_STATE;
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
-  ctrl_set_kernel<<<1, 1, 0, st>>>(d->ctrl, d->steps_done, 0, 1);
-  TTSX_LAUNCH_CHECK();
-  TTSX_HIP(hipMemsetAsync(d->n_steps_tmp, 0, sizeof(int32_t) * d->B, st));
-  StepOut o{frames, r, align, 1, stop, 1, d->n_steps_tmp};
-  int rc = enqueue_step(d, 0, r, o, memory, false, false, 2.f, st);
+  int rc = ensure_proj(d, r, st);
   if (rc) return rc;
-  rc = enqueue_stop_only(d, 0, r, o, false, 2.f, st);
+  RunCtx* h = d->rc_host;
+  h->base = d->steps_done, h->out_base = 0, h->all_done = 0, h->n_done = 0;
+  h->r = r, h->free_running = 0, h->threshold = 2.f;
+  h->mel = frames, h->mel_rows = r, h->align = align, h->align_rows = 1, h->stop = stop, h->stop_rows = 1;
+  // n_steps bookkeeping is not wanted here: point it at the energies scratch, never read back
+  h->n_steps = reinterpret_cast<int32_t*>(d->energies);
+  TTSX_HIP(hipMemsetAsync(d->energies, 0, sizeof(float) * d->B, st));
+  rc = push_ctx(d, st);
+  if (rc) return rc;
+  prenet1_explicit_kernel<<<ceil_div(d->B * PRENET_DIM, 256), 256, 0, st>>>(d->x1, memory, d->a1f, d->b1f, d->B,
+                                                                           d->Bpad);
+  TTSX_LAUNCH_CHECK();
+  rc = enqueue_step(d, 0, st);
   if (rc) return rc;
   d->steps_done += 1;
   return TTSX_OK;
@@ -839,34 +1087,32 @@ extern "C" int ttsx_t2_decoder_run(ttsx_t2_decoder* d, const float* enc, const i
   TTSX_ARG(r >= 1 && r <= d->r_init, "ttsx_t2_decoder_run: r=%d outside 1..%d", r, d->r_init);
   TTSX_ARG(max_steps >= 1, "ttsx_t2_decoder_run: max_steps=%d", max_steps);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  int rc = ttsx_t2_decoder_begin(d, enc, enc_len, B, T, stream);
+  int rc = ensure_proj(d, r, st);
+  if (rc) return rc;
+  rc = ttsx_t2_decoder_begin(d, enc, enc_len, B, T, stream);
   if (rc) return rc;
   TTSX_HIP(hipMemsetAsync(n_steps, 0, sizeof(int32_t) * B, st));
-  StepOut o{mel, max_steps * r, align, max_steps, stop, max_steps, n_steps};
-  const bool free_running = !fixed_steps;
-  const int CHUNK = 32;
+  RunCtx* h = d->rc_host;
+  h->r = r, h->free_running = fixed_steps ? 0 : 1, h->threshold = stop_threshold;
+  h->mel = mel, h->mel_rows = max_steps * r, h->align = align, h->align_rows = max_steps;
+  h->stop = stop, h->stop_rows = max_steps, h->n_steps = n_steps;
+  rc = push_ctx(d, st);
+  if (rc) return rc;
   int launched = 0;
   d->host_flag[0] = 0;
   while (launched < max_steps) {
     const int n = std::min(CHUNK, max_steps - launched);
-    for (int i = 0; i < n; ++i) {
-      rc = enqueue_step(d, i, r, o, nullptr, i > 0, free_running, stop_threshold, st);
-      if (rc) return rc;
-    }
-    rc = enqueue_stop_only(d, n - 1, r, o, free_running, stop_threshold, st);
+    rc = launch_chunk(d, n, st);
     if (rc) return rc;
-    ctrl_advance_kernel<<<1, 1, 0, st>>>(d->ctrl, n);
-    TTSX_LAUNCH_CHECK();
     launched += n;
-    if (free_running) {
-      TTSX_HIP(hipMemcpyAsync(d->host_flag, &d->ctrl->all_done, sizeof(int), hipMemcpyDeviceToHost, st));
+    if (!fixed_steps) {
+      TTSX_HIP(hipMemcpyAsync(d->host_flag, &d->rc->all_done, sizeof(int), hipMemcpyDeviceToHost, st));
       TTSX_HIP(hipStreamSynchronize(st));
       if (d->host_flag[0]) break;
     }
   }
-  finalize_steps_kernel<<<ceil_div(B, 256), 256, 0, st>>>(n_steps, B, d->ctrl, launched);
+  finalize_steps_kernel<<<ceil_div(B, 256), 256, 0, st>>>(n_steps, B, launched);
   TTSX_LAUNCH_CHECK();
-  // steps actually executed = max over utterances of n_steps
   std::vector<int32_t> host(B);
   TTSX_HIP(hipMemcpyAsync(host.data(), n_steps, sizeof(int32_t) * B, hipMemcpyDeviceToHost, st));
   TTSX_HIP(hipStreamSynchronize(st));
@@ -875,6 +1121,6 @@ extern "C" int ttsx_t2_decoder_run(ttsx_t2_decoder* d, const float* enc, const i
   if (fixed_steps) run = launched;
   if (steps_run_host) *steps_run_host = run;
   d->steps_done = run;
-  d->begun = false;  // the state belongs to a finished utterance batch
+  d->begun = false;  // the state belongs to a finished batch
   return TTSX_OK;
 }
