@@ -148,6 +148,32 @@ int ttsx_postnet_destroy(ttsx_postnet* p);
 int ttsx_postnet_run(ttsx_postnet* p, const float* mel, const int32_t* n_frames, int B, int F, float* out,
                      void* stream);
 
+/* ------------------------------------------------------------------ Tacotron2 encoder convolutions
+ * Replaces the three ConvBNBlocks of Encoder.inference: Tacotron2/TTS/models.py:449-451 with
+ * :380-400 (conv1d k=5, 512->512, + BatchNorm (eval) + ReLU; dropout is identity in eval).
+ * Tensor names are the state_dict keys under "encoder.convolutions.i.".  The embedding lookup
+ * and the BiLSTM around it stay stock PyTorch ops.
+ */
+typedef struct {
+  const float* conv_w[3];   /* net.0.weight [512,512,5] */
+  const float* conv_b[3];   /* net.0.bias   [512] */
+  const float* bn_weight[3];/* net.1.weight / bias / running_mean / running_var [512] */
+  const float* bn_bias[3];
+  const float* bn_mean[3];
+  const float* bn_var[3];
+} ttsx_encoder_conv_weights;
+
+typedef struct ttsx_encoder_convs ttsx_encoder_convs;
+
+int ttsx_encoder_convs_create(const ttsx_encoder_conv_weights* w, void* stream, ttsx_encoder_convs** out);
+int ttsx_encoder_convs_destroy(ttsx_encoder_convs* p);
+/*   x        [B,T,512] embedded text, position-major (embedding output as it is)
+ *   lengths  [B] int32 valid positions per utterance or NULL (= T); positions >= length are
+ *            treated as absent (zero padding), as a batch-1 run of the unpadded text gives
+ *   out      [B,T,512]                                                                  */
+int ttsx_encoder_convs_run(ttsx_encoder_convs* p, const float* x, const int32_t* lengths, int B, int T, float* out,
+                           void* stream);
+
 /* ------------------------------------------------------------------ vocoder (Griffin-Lim)
  * Replaces the inverse path of AudioProcessor: Tacotron2/TTS/utils.py:834-851
  * (_denormalize), 866-868 (_db_to_amp), 802-804 (_mel_to_linear), 922-929

@@ -10,7 +10,7 @@ def test_library_exports_every_declared_symbol():
     from tts_amd import _lib
     header = open(os.path.join(ROOT, "include", "ttsx.h")).read()
     declared = set(re.findall(r"\b(ttsx_[a-z0-9_]+)\s*\(", header))
-    declared -= {"ttsx_t2_decoder_weights", "ttsx_postnet_weights"}
+    declared -= {"ttsx_t2_decoder_weights", "ttsx_postnet_weights", "ttsx_encoder_conv_weights"}
     assert len(declared) >= 15
     assert os.path.exists(_lib.LIB_PATH), "build libttsx.so first (make -C tts_amd/csrc)"
     lib = ctypes.CDLL(_lib.LIB_PATH)
@@ -25,6 +25,7 @@ def test_struct_layouts_match_header():
     # 5 pairs of prenet pointers + 18 single pointers
     assert ctypes.sizeof(_lib.T2DecoderWeights) == 8 * (10 + 18)
     assert ctypes.sizeof(_lib.PostnetWeights) == 8 * 30
+    assert ctypes.sizeof(_lib.EncoderConvWeights) == 8 * 18
     assert ctypes.sizeof(_lib.StftParams) == 16
     assert ctypes.sizeof(_lib.AudioParams) == 28
 

@@ -8,7 +8,7 @@ import os
 from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libttsx.so")
+LIB_PATH = os.path.join(_HERE, os.environ.get("TTSX_LIB", "libttsx.so"))
 
 OK, ERR_ARG, ERR_HIP, ERR_STATE = 0, -1, -2, -3
 NORM_SOFTMAX, NORM_SIGMOID = 0, 1
@@ -32,6 +32,11 @@ class T2DecoderWeights(Structure):
 class PostnetWeights(Structure):
     _fields_ = [("conv_w", _fp * 5), ("conv_b", _fp * 5), ("bn_weight", _fp * 5), ("bn_bias", _fp * 5),
                 ("bn_mean", _fp * 5), ("bn_var", _fp * 5)]
+
+
+class EncoderConvWeights(Structure):
+    _fields_ = [("conv_w", _fp * 3), ("conv_b", _fp * 3), ("bn_weight", _fp * 3), ("bn_bias", _fp * 3),
+                ("bn_mean", _fp * 3), ("bn_var", _fp * 3)]
 
 
 class StftParams(Structure):
@@ -59,6 +64,9 @@ PROTOTYPES = {
     "ttsx_postnet_create": (c_int, [POINTER(PostnetWeights), c_void_p, POINTER(c_void_p)]),
     "ttsx_postnet_destroy": (c_int, [c_void_p]),
     "ttsx_postnet_run": (c_int, [c_void_p, _fp, _fp, c_int, c_int, _fp, c_void_p]),
+    "ttsx_encoder_convs_create": (c_int, [POINTER(EncoderConvWeights), c_void_p, POINTER(c_void_p)]),
+    "ttsx_encoder_convs_destroy": (c_int, [c_void_p]),
+    "ttsx_encoder_convs_run": (c_int, [c_void_p, _fp, _fp, c_int, c_int, _fp, c_void_p]),
     "ttsx_spec_to_mag": (c_int, [_fp, _fp, c_int, c_int, c_int, c_int, POINTER(AudioParams), _fp, c_void_p]),
     "ttsx_griffin_lim": (c_int, [_fp, _fp, _fp, c_int, c_int, POINTER(StftParams), c_int, c_float, _fp,
                                  c_void_p]),

@@ -1,9 +1,4 @@
-// Batched Griffin-Lim for gfx950: LDS-resident radix-4 Stockham FFTs (a 2048-point real
-// transform computed as a 1024-point complex one), with the analysis window, the phase
-// projection onto the target magnitudes, the inverse transform and the synthesis window
-// fused into one kernel per iteration.  Overlap-add is done as a gather when the next
-// iteration (or the final pass) reads the windowed frames, so no atomics are needed and
-// the result is bit-reproducible.
+// Batched Griffin-Lim for gfx950.
 //
 // Follows AudioProcessor._griffin_lim / _stft / _istft / inv_mel_spectrogram /
 // inv_spectrogram / apply_inv_preemphasis (Tacotron2/TTS/utils.py:896-942, 834-878,
@@ -11,6 +6,16 @@
 // stft/istft: centre padding by n_fft/2 ('constant' or 'reflect'), periodic Hann window of
 // win_length zero-padded centrally to n_fft, overlap-add divided by the window sum-square
 // where it exceeds float32 tiny, n_fft/2 samples trimmed at both ends.
+//
+// Structure of one iteration (two launches):
+//   frame kernel  one WAVE per frame, four frames per workgroup, no workgroup barriers in the
+//                 loop: windowed frame -> 2048-point real FFT (as a 1024-point complex FFT,
+//                 radix 16 x 16 x 4, 16 points per lane in registers, LDS only for the
+//                 transposes between passes) -> unit phasor x target magnitude -> inverse FFT
+//                 -> synthesis window -> windowed frame written to HBM.
+//   ola kernel    streaming overlap-add of the windowed frames (a gather, no atomics, so the
+//                 result is bit-reproducible), window-sum-square normalisation and centre
+//                 padding, producing the padded signal the next frame kernel reads.
 #include <math.h>
 
 #include <mutex>
@@ -20,253 +25,392 @@
 
 namespace {
 
-constexpr int NFFT = 2048, MC = 1024, NBIN = 1025, FFT_THREADS = 256;
-constexpr int WP = 1104;  // row pitch of the windowed-frame buffer (>= win_length, 16-byte multiple)
+constexpr int NFFT = 2048, MC = 1024, NBIN = 1025;
+constexpr int WP = 1104;          // row pitch of the windowed-frame buffer (floats)
+constexpr int FR_PER_WG = 4;      // frames (waves) per workgroup
+constexpr int LDS_PER_FR = MC + MC / 16;  // float2 per frame, padded by one every 16 against bank conflicts
 
 struct Tables {
-  float2* tw;   // W_2048^m = exp(-2 pi i m / 2048), m = 0..2047
-  float* win[2];
+  float2* tw;    // W_2048^m = exp(-2 pi i m / 2048), m = 0..1023
+  float* win[2]; // periodic Hann of win_length, zero-padded centrally to 2048
   int win_len[2];
 };
 Tables g_tab = {nullptr, {nullptr, nullptr}, {0, 0}};
 std::mutex g_tab_mu;
 
-__device__ inline float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
-__device__ inline float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
-__device__ inline float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ inline float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+  return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ int pidx(int i) { return i + (i >> 4); }
 
-// 1024-point complex FFT, 256 threads, radix-4 Stockham autosort, 5 passes.  Input in `a`
-// (must be complete: caller syncs), output in `b`.  SIGN = -1 forward, +1 inverse (unscaled).
+// 4-point DFT in place; SIGN = -1 forward, +1 inverse
 template <int SIGN>
-__device__ inline void fft1024(float2* a, float2* b, const float2* __restrict__ tw, int tid) {
-  float2* src = a;
-  float2* dst = b;
+__device__ __forceinline__ void dft4(float2& a, float2& b, float2& c, float2& d) {
+  const float2 s0 = cadd(a, c), d0 = csub(a, c), s1 = cadd(b, d), d1 = csub(b, d);
+  const float2 jd1 = SIGN < 0 ? make_float2(d1.y, -d1.x) : make_float2(-d1.y, d1.x);  // -+ i * d1
+  a = cadd(s0, s1);
+  b = cadd(d0, jd1);
+  c = csub(s0, s1);
+  d = csub(d0, jd1);
+}
+
+// 16-point DFT of v[r] (r = time index) in registers; result X[q] is left in v[q].
+template <int SIGN>
+__device__ __forceinline__ void dft16(float2 (&v)[16]) {
+  // r = r1 + 4 r2: DFT over r2 for each r1
 #pragma unroll
-  for (int p = 0; p < 5; ++p) {
-    const int Ns = 1 << (2 * p);
-    const int k = tid & (Ns - 1);
-    float2 v0 = src[tid], v1 = src[tid + 256], v2 = src[tid + 512], v3 = src[tid + 768];
-    if (p > 0) {
-      const int m = k * (512 >> (2 * p));
-      float2 w1 = tw[m], w2 = tw[2 * m], w3 = tw[3 * m];
-      if (SIGN > 0) w1 = cconj(w1), w2 = cconj(w2), w3 = cconj(w3);
-      v1 = cmul(v1, w1), v2 = cmul(v2, w2), v3 = cmul(v3, w3);
+  for (int r1 = 0; r1 < 4; ++r1) dft4<SIGN>(v[r1], v[r1 + 4], v[r1 + 8], v[r1 + 12]);
+  // now v[r1 + 4 q2] = A[r1][q2]; multiply by W16^(r1 q2)
+  constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, C2 = 0.70710678118654752f;
+  const float sg = SIGN < 0 ? -1.f : 1.f;
+  // W16^m = (cos(pi m/8), sg*sin(pi m/8))
+  const float2 w1 = make_float2(C1, sg * S1), w2 = make_float2(C2, sg * C2), w3 = make_float2(S1, sg * C1);
+  const float2 w4 = make_float2(0.f, sg), w6 = make_float2(-C2, sg * C2), w9 = make_float2(-C1, -sg * S1);
+  v[1 + 4] = cmul(v[1 + 4], w1);
+  v[2 + 4] = cmul(v[2 + 4], w2);
+  v[3 + 4] = cmul(v[3 + 4], w3);
+  v[1 + 8] = cmul(v[1 + 8], w2);
+  v[2 + 8] = cmul(v[2 + 8], w4);
+  v[3 + 8] = cmul(v[3 + 8], w6);
+  v[1 + 12] = cmul(v[1 + 12], w3);
+  v[2 + 12] = cmul(v[2 + 12], w6);
+  v[3 + 12] = cmul(v[3 + 12], w9);
+  // DFT over r1 for each q2: X[4 q1 + q2]
+#pragma unroll
+  for (int q2 = 0; q2 < 4; ++q2) dft4<SIGN>(v[4 * q2], v[4 * q2 + 1], v[4 * q2 + 2], v[4 * q2 + 3]);
+  // v[4 q2 + q1] holds X[4 q1 + q2]: transpose the 4x4 index
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = a + 1; b < 4; ++b) {
+      const float2 t = v[4 * a + b];
+      v[4 * a + b] = v[4 * b + a];
+      v[4 * b + a] = t;
     }
-    const float2 s0 = cadd(v0, v2), d0 = csub(v0, v2), s1 = cadd(v1, v3), d1 = csub(v1, v3);
-    // forward: -i*d1 = (d1.y, -d1.x); inverse: +i*d1 = (-d1.y, d1.x)
-    const float2 jd1 = SIGN < 0 ? make_float2(d1.y, -d1.x) : make_float2(-d1.y, d1.x);
-    const int j0 = ((tid >> (2 * p)) << (2 * p + 2)) + k;
-    dst[j0] = cadd(s0, s1);
-    dst[j0 + Ns] = cadd(d0, jd1);
-    dst[j0 + 2 * Ns] = csub(s0, s1);
-    dst[j0 + 3 * Ns] = csub(d0, jd1);
-    __syncthreads();
-    float2* t = src;
-    src = dst;
-    dst = t;
+}
+
+// W_1024^m = exp(-2 pi i m / 1024) (m < 1024) from the LDS table; conjugated for the inverse
+template <int SIGN>
+__device__ __forceinline__ float2 tw1024(const float2* s_tw, int m) {
+  const float2 w = s_tw[m];
+  return SIGN < 0 ? w : cconj(w);
+}
+
+// Passes 2 and 3 of the 1024-point FFT of one wave.  On entry v[r] holds, for lane j, the
+// output of the first radix-16 pass (butterfly j, Stockham order); on exit v[4 i + r] holds
+// element (lane + 64 i) + 256 r of the result.  LDS addresses are written as a per-lane base
+// plus a compile-time constant (pidx(lane + 64 r) = lane + (lane >> 4) + 68 r, etc.) so that
+// they fold into instruction offsets; `z` is an opaque zero that keeps the twiddle loads
+// inside the frame loop (hoisting them costs ~60 registers and an occupancy step).
+template <int SIGN>
+__device__ __forceinline__ void fft1024_tail(float2 (&v)[16], float2* s, const float2* s_tw, int lane, int z) {
+  const int bl = lane + (lane >> 4);  // pidx(lane)
+  // pass 1 store: dst[j*16 + r] -> pidx = 17 j + r
+#pragma unroll
+  for (int r = 0; r < 16; ++r) s[17 * lane + r] = v[r];
+  // pass 2: Ns = 16, k = j % 16, twiddle W_256^(k r) = W_1024^(4 k r)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) v[r] = s[bl + 68 * r];
+  const int k = lane & 15;
+#pragma unroll
+  for (int r = 1; r < 16; ++r) v[r] = cmul(v[r], tw1024<SIGN>(s_tw, 4 * k * r + z));
+  dft16<SIGN>(v);
+  const int j0 = (lane >> 4) * 256 + k;
+  const int bj = j0 + (j0 >> 4);  // pidx(j0 + 16 r) = bj + 17 r
+#pragma unroll
+  for (int r = 0; r < 16; ++r) s[bj + 17 * r] = v[r];
+  // pass 3: radix 4, Ns = 256, four butterflies per lane: j = lane + 64 i; pidx(j + 256 r) = bl + 68 i + 272 r
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[4 * i + r] = s[bl + 68 * i + 272 * r];
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int j = lane + 64 * i + z;
+    v[4 * i + 1] = cmul(v[4 * i + 1], tw1024<SIGN>(s_tw, j));
+    v[4 * i + 2] = cmul(v[4 * i + 2], tw1024<SIGN>(s_tw, 2 * j));
+    v[4 * i + 3] = cmul(v[4 * i + 3], tw1024<SIGN>(s_tw, 3 * j));
+    dft4<SIGN>(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
   }
 }
 
 // unit phasor of z with np.angle(0) = 0 semantics
-__device__ inline float2 unit_phase(float2 z) {
+__device__ __forceinline__ float2 unit_phase(float2 z) {
   const float r = fmaxf(fabsf(z.x), fabsf(z.y));
   if (!(r > 0.f)) return make_float2(1.f, 0.f);
-  const float a = z.x / r, b = z.y / r;
-  const float n = 1.0f / sqrtf(a * a + b * b);
+  const float ir = __builtin_amdgcn_rcpf(r);   // prescale by the larger component: no overflow / underflow
+  const float a = z.x * ir, b = z.y * ir;
+  const float n = __builtin_amdgcn_rsqf(a * a + b * b);
   return make_float2(a * n, b * n);
 }
 
 struct FrameGeom {
   int hop, win, lpad;  // lpad = (n_fft - win) / 2
   int pad_mode;
+  int LP;              // padded signal length per utterance: n_fft + hop*(F-1), rounded up to 4
 };
-
-// Overlap-added, window-normalised signal at padded index g (0 <= g < n_fft + hop*(F-1)),
-// gathered from the windowed frames yw[F][WP] of one utterance.  Frames are summed in
-// increasing order in fp32, as the reference's frame-by-frame accumulation does.
-__device__ inline float ola_sample(const float* __restrict__ yw, const float* __restrict__ s_win, int g, int F,
-                                   const FrameGeom& q) {
-  const int rel = g - q.lpad;
-  if (rel < 0) return 0.f;
-  int hi = rel / q.hop;
-  if (hi > F - 1) hi = F - 1;
-  int lo = rel - q.win + 1;
-  lo = lo <= 0 ? 0 : (lo + q.hop - 1) / q.hop;
-  float acc = 0.f, wss = 0.f;
-  for (int i = lo; i <= hi; ++i) {
-    const int n = rel - i * q.hop;
-    acc += yw[(size_t)i * WP + n];
-    const float w = s_win[n];
-    wss += w * w;
-  }
-  if (wss > 1.17549435e-38f) acc /= wss;
-  return acc;
-}
-
-// value of the centre-padded signal at padded index g, signal length L = hop*(F-1)
-template <typename SampleFn>
-__device__ inline float padded_sample(int g, int L, int pad_mode, SampleFn sample) {
-  int m = g - NFFT / 2;
-  if (m < 0 || m >= L) {
-    if (pad_mode == TTSX_PAD_CONSTANT || L <= 1) return 0.f;
-    const int period = 2 * (L - 1);
-    m %= period;
-    if (m < 0) m += period;
-    if (m >= L) m = period - m;
-  }
-  return sample(m);
-}
 
 enum { K_GL_INIT = 0, K_GL_ITER = 1, K_STFT = 2, K_ISTFT = 3 };
 
 struct FrameP {
   const float* mag;      // [B][F][NBIN]           (GL)
   const float* phase01;  // [B][F][NBIN]           (GL_INIT)
-  const float* yw_in;    // [B][F][WP]             (GL_ITER)
-  float* yw_out;         // [B][F][WP]             (GL_*, ISTFT)
-  const float* y_in;     // [B][hop*(F-1)]         (STFT)
+  const float* ypad;     // [B][LP]                (GL_ITER, STFT)
+  float* yw_out;         // [B][F][WP]             (GL_*, ISTFT): samples lpad_even .. lpad_even+WP of each frame
   float* spec_re;        // [B][F][NBIN]           (STFT out / ISTFT in)
   float* spec_im;
   const int32_t* n_frames;
   const float2* tw;
-  const float* win;
+  const float* winpad;   // [2048]
   int B, F;
   FrameGeom q;
 };
 
 template <int KIND>
-__global__ __launch_bounds__(FFT_THREADS) void frame_kernel(FrameP p) {
-  __shared__ float2 s_a[MC];
-  __shared__ float2 s_b[MC];
-  __shared__ float2 s_tw[NFFT];
-  __shared__ float s_win[WP];
-  const int tid = threadIdx.x;
-  for (int i = tid; i < NFFT; i += FFT_THREADS) s_tw[i] = p.tw[i];
-  for (int i = tid; i < WP; i += FFT_THREADS) s_win[i] = i < p.q.win ? p.win[i] : 0.f;
+__global__ __launch_bounds__(64 * FR_PER_WG, 3) void frame_kernel(FrameP p) {
+  __shared__ float2 s_tw[1024];   // W_1024^m
+  __shared__ float2 s_tw2[516];   // W_2048^k, k <= 512 (real-transform post/pre-processing)
+  __shared__ float2 s_data[FR_PER_WG][LDS_PER_FR];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  for (int i = tid; i < 1024; i += 64 * FR_PER_WG) {
+    const float2 w = p.tw[(2 * i) & 1023];  // W_1024^i = W_2048^(2i), and W_1024^(i+512) = -W_1024^i
+    s_tw[i] = i >= 512 ? make_float2(-w.x, -w.y) : w;
+  }
+  for (int i = tid; i <= 512; i += 64 * FR_PER_WG) s_tw2[i] = p.tw[i];
   __syncthreads();
   const FrameGeom q = p.q;
   const long total = (long)p.B * p.F;
+  float2* s = s_data[wave];
+  // the padded window (8 KiB) stays L1-resident: read it through the vector cache, not LDS
+  const float2* s_win2 = reinterpret_cast<const float2*>(p.winpad);
 
-  for (long fi = blockIdx.x; fi < total; fi += gridDim.x) {
+  for (long fi = (long)blockIdx.x * FR_PER_WG + wave; fi < total; fi += (long)gridDim.x * FR_PER_WG) {
     const int b = (int)(fi / p.F), i = (int)(fi % p.F);
     const int Fb = p.n_frames ? p.n_frames[b] : p.F;
-    if (i >= Fb) continue;  // uniform per block
-    const int L = q.hop * (Fb - 1);
+    if (i >= Fb) continue;  // wave-uniform
     const size_t frow = (size_t)b * p.F + i;
+    float2 v[16];
+    int z = 0;
+    asm volatile("" : "+v"(z));  // opaque zero: pins loop-invariant table loads inside the loop
+    // opaque per-phase copies of the lane id: addresses derived from them are recomputed inside
+    // their phase instead of staying live across the whole loop body
+    int lane_a = lane, lane_b = lane, lane_s = lane;
+    asm volatile("" : "+v"(lane_a), "+v"(lane_b), "+v"(lane_s));
 
     if (KIND == K_GL_ITER || KIND == K_STFT) {
-      // ---- analysis: windowed frame -> packed complex -> FFT -> half spectrum
-      for (int m = tid; m < MC; m += FFT_THREADS) s_a[m] = make_float2(0.f, 0.f);
-      __syncthreads();
-      float* s_real = reinterpret_cast<float*>(s_a);  // x[2m] = re, x[2m+1] = im
-      for (int n = tid; n < q.win; n += FFT_THREADS) {
-        const int g = i * q.hop + q.lpad + n;
-        float v;
-        if (KIND == K_GL_ITER) {
-          const float* yw = p.yw_in + (size_t)b * p.F * WP;
-          v = padded_sample(g, L, q.pad_mode, [&](int m) { return ola_sample(yw, s_win, m + NFFT / 2, Fb, q); });
-        } else {
-          const float* y = p.y_in + (size_t)b * q.hop * (p.F - 1);
-          v = padded_sample(g, L, q.pad_mode, [&](int m) { return y[m]; });
+      // ---- analysis: z[m] = (x[2m], x[2m+1]) windowed, first radix-16 pass straight from HBM
+      const float* src = p.ypad + (size_t)b * q.LP + (size_t)i * q.hop;
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        // four groups of loads, fenced so that at most one group's operands are live at a time
+#pragma unroll
+        for (int r = 4 * h; r < 4 * h + 4; ++r) {
+          const int m = lane_a + 64 * r;
+          const float2 w = s_win2[m + z];
+          // the hop is odd in general: two 4-byte loads
+#ifdef EXP_NOLOAD
+          v[r] = make_float2((float)(m + z) * w.x, (float)(m - z) * w.y);
+#else
+          v[r] = make_float2(src[2 * m] * w.x, src[2 * m + 1] * w.y);
+#endif
         }
-        s_real[q.lpad + n] = v * s_win[n];
+        __builtin_amdgcn_sched_barrier(0);
       }
-      __syncthreads();
-      fft1024<-1>(s_a, s_b, s_tw, tid);  // result in s_b
+      dft16<-1>(v);
+      fft1024_tail<-1>(v, s, s_tw, lane_a, z);
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[lane_a + (lane_a >> 4) + 68 * c + 272 * r] = v[4 * c + r];
     }
 
-    // ---- per-bin work on pairs (k, 1024-k); thread handles k = tid, tid+256 and (tid==0) 512
-    for (int kk = 0; kk < 3; ++kk) {
+    // ---- per-bin work on pairs (k, 1024-k): k = lane + 64 c (c < 8), and bin 512 on lane 0
+    const float* mg = p.mag + frow * NBIN;
+#pragma unroll 3
+    for (int c = 0; c < 9; ++c) {
       int k;
-      if (kk < 2) k = tid + kk * 256;
-      else if (tid == 0) k = 512;
+      if (c < 8) k = lane_b + 64 * c;
+      else if (lane_b == 0) k = 512;
       else break;
-      const int mk = MC - k;  // partner bin (1024 for k = 0)
+      const int mkk = MC - k;  // partner bin (1024 for k = 0)
       float2 Xk, Xm;
       if (KIND == K_GL_ITER || KIND == K_STFT) {
-        const float2 Zk = s_b[k], Zm = s_b[mk & (MC - 1)];
+        const float2 Zk = s[pidx(k)], Zm = s[pidx(mkk & (MC - 1))];
         const float2 E = make_float2(0.5f * (Zk.x + Zm.x), 0.5f * (Zk.y - Zm.y));
         const float2 D = make_float2(0.5f * (Zk.x - Zm.x), 0.5f * (Zk.y + Zm.y));  // (Zk - conj(Zm))/2
         const float2 O = make_float2(D.y, -D.x);                                  // -i * D
-        const float2 WO = cmul(s_tw[k], O);
+        const float2 WO = cmul(s_tw2[k + z], O);
         Xk = cadd(E, WO);
         Xm = cconj(csub(E, WO));
       }
       if (KIND == K_STFT) {
         p.spec_re[frow * NBIN + k] = Xk.x, p.spec_im[frow * NBIN + k] = Xk.y;
-        p.spec_re[frow * NBIN + mk] = Xm.x, p.spec_im[frow * NBIN + mk] = Xm.y;
+        p.spec_re[frow * NBIN + mkk] = Xm.x, p.spec_im[frow * NBIN + mkk] = Xm.y;
         continue;
       }
+      float sk = 0.f, sm = 0.f;
+#ifdef EXP_NOMAG
+      if (KIND == K_GL_ITER || KIND == K_GL_INIT) sk = 1.f + z, sm = 2.f + z;
+#else
+      if (KIND == K_GL_ITER || KIND == K_GL_INIT) sk = mg[k], sm = mg[mkk];
+#endif
       if (KIND == K_GL_ITER) {
         const float2 uk = unit_phase(Xk), um = unit_phase(Xm);
-        const float sk = p.mag[frow * NBIN + k], sm = p.mag[frow * NBIN + mk];
         Xk = make_float2(sk * uk.x, sk * uk.y);
         Xm = make_float2(sm * um.x, sm * um.y);
       } else if (KIND == K_GL_INIT) {
-        const float sk = p.mag[frow * NBIN + k], sm = p.mag[frow * NBIN + mk];
         float sn, cs;
         sincospif(2.0f * p.phase01[frow * NBIN + k], &sn, &cs);
         Xk = make_float2(sk * cs, sk * sn);
-        sincospif(2.0f * p.phase01[frow * NBIN + mk], &sn, &cs);
+        sincospif(2.0f * p.phase01[frow * NBIN + mkk], &sn, &cs);
         Xm = make_float2(sm * cs, sm * sn);
       } else {  // K_ISTFT
         Xk = make_float2(p.spec_re[frow * NBIN + k], p.spec_im[frow * NBIN + k]);
-        Xm = make_float2(p.spec_re[frow * NBIN + mk], p.spec_im[frow * NBIN + mk]);
+        Xm = make_float2(p.spec_re[frow * NBIN + mkk], p.spec_im[frow * NBIN + mkk]);
       }
       if (k == 0) Xk.y = 0.f, Xm.y = 0.f;  // the inverse real transform ignores Im of DC and Nyquist
-      // ---- synthesis pre-pass: Z[k] = E + iO, Z[1024-k] = conj(E) + i conj(O)
+      // synthesis pre-pass: Z[k] = E + iO, Z[1024-k] = conj(E) + i conj(O)
       const float2 E = make_float2(0.5f * (Xk.x + Xm.x), 0.5f * (Xk.y - Xm.y));
       const float2 D = make_float2(0.5f * (Xk.x - Xm.x), 0.5f * (Xk.y + Xm.y));
-      const float2 O = cmul(D, cconj(s_tw[k]));
-      s_a[k] = make_float2(E.x - O.y, E.y + O.x);
-      if (k != 0) s_a[mk] = make_float2(E.x + O.y, -E.y + O.x);
+      const float2 O = cmul(D, cconj(s_tw2[k + z]));
+      s[pidx(k)] = make_float2(E.x - O.y, E.y + O.x);
+      if (k != 0) s[pidx(mkk)] = make_float2(E.x + O.y, -E.y + O.x);
     }
-    if (KIND == K_STFT) {
-      __syncthreads();
-      continue;
-    }
-    __syncthreads();
-    fft1024<+1>(s_a, s_b, s_tw, tid);  // result in s_b, unscaled
+    if (KIND == K_STFT) continue;
+
+    // ---- synthesis: inverse FFT, window, store the windowed frame
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = s[lane_s + (lane_s >> 4) + 68 * r];
+    dft16<+1>(v);
+    fft1024_tail<+1>(v, s, s_tw, lane_s, z);
     {
-      const float* s_real = reinterpret_cast<const float*>(s_b);
+      const int lpe = q.lpad & ~1;
       float* dst = p.yw_out + frow * WP;
       const float scale = 1.0f / MC;
-      for (int n = tid; n < q.win; n += FFT_THREADS) dst[n] = s_real[q.lpad + n] * scale * s_win[n];
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = lane_s + 64 * c + 256 * r;  // complex index -> samples 2m, 2m+1
+          const int n = 2 * m - lpe;
+#ifdef EXP_NOSTORE
+          if (n == -12345) {
+#else
+          if (n >= 0 && n < WP) {
+#endif
+            const float2 w = s_win2[m + z];
+            *reinterpret_cast<float2*>(dst + n) = make_float2(v[4 * c + r].x * scale * w.x, v[4 * c + r].y * scale * w.y);
+          }
+        }
     }
-    __syncthreads();
   }
 }
 
-// final overlap-add: y[b][m] for m < hop*(F_b - 1), zero beyond
-__global__ void ola_kernel(float* __restrict__ y, const float* __restrict__ yw, const float* __restrict__ win,
-                           const int32_t* __restrict__ n_frames, int B, int F, FrameGeom q) {
-  __shared__ float s_win[WP];
-  for (int i = threadIdx.x; i < WP; i += blockDim.x) s_win[i] = i < q.win ? win[i] : 0.f;
-  __syncthreads();
+// Overlap-add of the windowed frames, window-sum-square normalisation (where it exceeds float32
+// tiny) and the zero part of the centre padding.  One workgroup per hop-sized slot s: padded
+// indices g = lpad + s*hop + rho, rho < hop, receive frame s-k at in-window position k*hop + rho
+// for k = 0 .. ceil(win/hop)-1.  Frames are summed in increasing order in fp32, as the reference's
+// frame-by-frame accumulation does.  No divisions, every access coalesced.
+// PADDED = 1: out[b][g] over the centre-padded signal (what the next STFT reads), zeros in the pad;
+// PADDED = 0: out[b][m] = trimmed signal (m = g - n_fft/2), zero beyond the utterance's own length.
+constexpr int OLA_MAXK = 8, OLA_SLOTS = 8;
+template <int PADDED>
+__global__ __launch_bounds__(320) void ola_kernel(float* __restrict__ out, const float* __restrict__ yw,
+                                                  const float* __restrict__ winpad,
+                                                  const int32_t* __restrict__ n_frames, int B, int F, FrameGeom q,
+                                                  int n_slots) {
   const int b = blockIdx.y;
   const int Fb = n_frames ? n_frames[b] : F;
-  const int Lmax = q.hop * (F - 1), L = q.hop * (Fb - 1);
-  const int m = blockIdx.x * blockDim.x + threadIdx.x;
-  if (m >= Lmax) return;
+  const int L = q.hop * (Fb - 1), Lmax = q.hop * (F - 1);
+  const float* ywb = yw + (size_t)b * F * WP;
+  const int K = (q.win + q.hop - 1) / q.hop;
+  const int shift = q.lpad - (q.lpad & ~1);
+  for (int s = blockIdx.x * OLA_SLOTS; s < min((int)(blockIdx.x + 1) * OLA_SLOTS, n_slots); ++s)
+  for (int rho = threadIdx.x; rho < q.hop; rho += blockDim.x) {
+    const int g = q.lpad + s * q.hop + rho;  // padded-buffer index
+    const int m = g - NFFT / 2;              // index in the trimmed signal
+    float acc = 0.f, wss = 0.f;
+    if (m >= 0 && m < L) {
+#pragma unroll
+      for (int kk = OLA_MAXK - 1; kk >= 0; --kk) {  // descending k = ascending frame index
+        const int i = s - kk, n = kk * q.hop + rho;
+        if (kk < K && i >= 0 && i < Fb && n < q.win) {
+          acc += ywb[(size_t)i * WP + n + shift];
+          const float w = winpad[q.lpad + n];
+          wss += w * w;
+        }
+      }
+      if (wss > 1.17549435e-38f) acc /= wss;
+    }
+    if (PADDED) {
+      if (g < q.LP) out[(size_t)b * q.LP + g] = acc;
+    } else {
+      if (m >= 0 && m < Lmax) out[(size_t)b * Lmax + m] = acc;
+    }
+  }
+  if (PADDED && blockIdx.x == 0) {
+    // the first lpad samples and the tail beyond the last slot belong to nobody's slot
+    for (int g = threadIdx.x; g < q.lpad; g += blockDim.x) out[(size_t)b * q.LP + g] = 0.f;
+    for (int g = q.lpad + n_slots * q.hop + threadIdx.x; g < q.LP; g += blockDim.x) out[(size_t)b * q.LP + g] = 0.f;
+  }
+}
+
+// 'reflect' centre padding: pad samples mirror the interior of the signal (np.pad mode='reflect')
+__global__ void reflect_pad_kernel(float* __restrict__ ypad, const int32_t* __restrict__ n_frames, int B, int F,
+                                   FrameGeom q) {
+  const int b = blockIdx.y;
+  const int Fb = n_frames ? n_frames[b] : F;
+  const int L = q.hop * (Fb - 1);
+  if (L <= 1) return;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;  // 0 .. n_fft-1: first half = head pad, second = tail pad
+  if (t >= NFFT) return;
+  const int g = t < NFFT / 2 ? t : NFFT / 2 + L + (t - NFFT / 2);
+  int m = g - NFFT / 2;
+  const int period = 2 * (L - 1);
+  m %= period;
+  if (m < 0) m += period;
+  if (m >= L) m = period - m;
+  float* yb = ypad + (size_t)b * q.LP;
+  yb[g] = yb[NFFT / 2 + m];
+}
+
+// centre padding of a given signal y[B][hop*(F-1)] (unit STFT entry point)
+__global__ void pad_signal_kernel(float* __restrict__ ypad, const float* __restrict__ y, int B, int F, FrameGeom q) {
+  const int b = blockIdx.y;
+  const int L = q.hop * (F - 1);
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= q.LP) return;
+  int m = g - NFFT / 2;
   float v = 0.f;
-  if (m < L) v = ola_sample(yw + (size_t)b * F * WP, s_win, m + NFFT / 2, Fb, q);
-  y[(size_t)b * Lmax + m] = v;
+  if (m >= 0 && m < L) {
+    v = y[(size_t)b * L + m];
+  } else if (q.pad_mode == TTSX_PAD_REFLECT && L > 1 && g < NFFT + L) {
+    const int period = 2 * (L - 1);
+    m %= period;
+    if (m < 0) m += period;
+    if (m >= L) m = period - m;
+    v = y[(size_t)b * L + m];
+  }
+  ypad[(size_t)b * q.LP + g] = v;
 }
 
 // de-emphasis y[n] = x[n] + a*y[n-1] (lfilter([1],[1,-a])).  The impulse response a^k falls
 // below 1e-17 after 2048 taps (a = 0.98), so each thread rebuilds the recurrence for its own
 // 256-sample segment from a 2048-sample warm-up, in fp64 like the reference.
 constexpr int DE_SEG = 256, DE_WARM = 2048;
-__global__ void deemph_kernel(float* __restrict__ out, const float* __restrict__ x, const int32_t* __restrict__ n_frames,
-                              int B, int F, int hop, float coef) {
+__global__ void deemph_kernel(float* __restrict__ out, const float* __restrict__ x, size_t x_pitch,
+                              const int32_t* __restrict__ n_frames, int B, int F, int hop, float coef) {
   const int b = blockIdx.y;
   const int Fb = n_frames ? n_frames[b] : F;
   const int Lmax = hop * (F - 1), L = hop * (Fb - 1);
   const int seg = blockIdx.x * blockDim.x + threadIdx.x;
   const int start = seg * DE_SEG;
   if (start >= Lmax) return;
-  const float* xb = x + (size_t)b * Lmax;
+  const float* xb = x + (size_t)b * x_pitch;
   float* ob = out + (size_t)b * Lmax;
   double acc = 0.0;
   const double a = (double)coef;
@@ -336,16 +480,16 @@ __global__ __launch_bounds__(256) void spec_to_mag_kernel(MagP p) {
   }
 }
 
-int get_tables(const ttsx_stft_params* sp, const float2** tw, const float** win, hipStream_t st) {
+int get_tables(const ttsx_stft_params* sp, const float2** tw, const float** winpad) {
   std::lock_guard<std::mutex> lock(g_tab_mu);
   if (!g_tab.tw) {
-    std::vector<float2> h(NFFT);
-    for (int m = 0; m < NFFT; ++m) {
+    std::vector<float2> h(1024);
+    for (int m = 0; m < 1024; ++m) {
       const double a = -2.0 * M_PI * (double)m / (double)NFFT;
       h[m] = make_float2((float)cos(a), (float)sin(a));
     }
-    TTSX_HIP(hipMalloc(reinterpret_cast<void**>(&g_tab.tw), NFFT * sizeof(float2)));
-    TTSX_HIP(hipMemcpy(g_tab.tw, h.data(), NFFT * sizeof(float2), hipMemcpyHostToDevice));
+    TTSX_HIP(hipMalloc(reinterpret_cast<void**>(&g_tab.tw), 1024 * sizeof(float2)));
+    TTSX_HIP(hipMemcpy(g_tab.tw, h.data(), 1024 * sizeof(float2), hipMemcpyHostToDevice));
   }
   int slot = -1;
   for (int s = 0; s < 2; ++s)
@@ -353,59 +497,64 @@ int get_tables(const ttsx_stft_params* sp, const float2** tw, const float** win,
   if (slot < 0) {
     slot = g_tab.win_len[0] == 0 ? 0 : 1;
     if (g_tab.win[slot]) (void)hipFree(g_tab.win[slot]);
-    // periodic Hann: scipy.signal.get_window('hann', win, fftbins=True)
-    std::vector<float> h(sp->win_length);
+    g_tab.win[slot] = nullptr;
+    // periodic Hann (scipy.signal.get_window('hann', win, fftbins=True)), padded centrally to n_fft
+    std::vector<float> h(NFFT, 0.f);
+    const int lpad = (NFFT - sp->win_length) / 2;
     for (int n = 0; n < sp->win_length; ++n)
-      h[n] = (float)(0.5 - 0.5 * cos(2.0 * M_PI * (double)n / (double)sp->win_length));
-    TTSX_HIP(hipMalloc(reinterpret_cast<void**>(&g_tab.win[slot]), sp->win_length * sizeof(float)));
-    TTSX_HIP(hipMemcpy(g_tab.win[slot], h.data(), sp->win_length * sizeof(float), hipMemcpyHostToDevice));
+      h[lpad + n] = (float)(0.5 - 0.5 * cos(2.0 * M_PI * (double)n / (double)sp->win_length));
+    TTSX_HIP(hipMalloc(reinterpret_cast<void**>(&g_tab.win[slot]), NFFT * sizeof(float)));
+    TTSX_HIP(hipMemcpy(g_tab.win[slot], h.data(), NFFT * sizeof(float), hipMemcpyHostToDevice));
     g_tab.win_len[slot] = sp->win_length;
   }
   *tw = g_tab.tw;
-  *win = g_tab.win[slot];
-  (void)st;
+  *winpad = g_tab.win[slot];
   return TTSX_OK;
 }
 
 int check_stft_params(const ttsx_stft_params* sp, int B, int F) {
   TTSX_ARG(sp, "stft params: null");
   TTSX_ARG(sp->n_fft == NFFT, "n_fft=%d unsupported (only %d)", sp->n_fft, NFFT);
-  TTSX_ARG(sp->win_length >= 2 && sp->win_length <= WP && sp->win_length <= NFFT,
-           "win_length=%d outside 2..%d", sp->win_length, WP);
+  TTSX_ARG(sp->win_length >= 2 && sp->win_length <= WP - 2, "win_length=%d outside 2..%d", sp->win_length, WP - 2);
   TTSX_ARG(sp->hop_length >= 1 && sp->hop_length <= sp->win_length, "hop_length=%d", sp->hop_length);
   TTSX_ARG(sp->pad_mode == TTSX_PAD_CONSTANT || sp->pad_mode == TTSX_PAD_REFLECT, "pad_mode=%d", sp->pad_mode);
   TTSX_ARG(B >= 1 && F >= 2, "bad shape B=%d F=%d (need at least 2 frames)", B, F);
   return TTSX_OK;
 }
 
-// scratch for the windowed frames: two buffers of B*F*WP floats, grown on demand
+FrameGeom make_geom(const ttsx_stft_params* sp, int F) {
+  FrameGeom q;
+  q.hop = sp->hop_length, q.win = sp->win_length, q.lpad = (NFFT - sp->win_length) / 2, q.pad_mode = sp->pad_mode;
+  q.LP = round_up(NFFT + sp->hop_length * (F - 1), 4);
+  return q;
+}
+
+// scratch shared by every call in the process: windowed frames and the padded signal
 struct Scratch {
-  float* yw[2];
-  float* y;
-  size_t cap_yw, cap_y;
+  float* yw;
+  float* ypad;
+  size_t cap_yw, cap_ypad;
 };
-Scratch g_scr = {{nullptr, nullptr}, nullptr, 0, 0};
+Scratch g_scr = {nullptr, nullptr, 0, 0};
 std::mutex g_scr_mu;
 
-int ensure_scratch(size_t n_yw, size_t n_y) {
+int ensure_scratch(size_t n_yw, size_t n_ypad) {
   if (n_yw > g_scr.cap_yw) {
-    for (int i = 0; i < 2; ++i) {
-      if (g_scr.yw[i]) (void)hipFree(g_scr.yw[i]);
-      g_scr.yw[i] = nullptr;
-      TTSX_HIP(hipMalloc(reinterpret_cast<void**>(&g_scr.yw[i]), n_yw * sizeof(float)));
-    }
+    if (g_scr.yw) (void)hipFree(g_scr.yw);
+    g_scr.yw = nullptr, g_scr.cap_yw = 0;
+    TTSX_HIP(hipMalloc(reinterpret_cast<void**>(&g_scr.yw), n_yw * sizeof(float)));
     g_scr.cap_yw = n_yw;
   }
-  if (n_y > g_scr.cap_y) {
-    if (g_scr.y) (void)hipFree(g_scr.y);
-    g_scr.y = nullptr;
-    TTSX_HIP(hipMalloc(reinterpret_cast<void**>(&g_scr.y), n_y * sizeof(float)));
-    g_scr.cap_y = n_y;
+  if (n_ypad > g_scr.cap_ypad) {
+    if (g_scr.ypad) (void)hipFree(g_scr.ypad);
+    g_scr.ypad = nullptr, g_scr.cap_ypad = 0;
+    TTSX_HIP(hipMalloc(reinterpret_cast<void**>(&g_scr.ypad), n_ypad * sizeof(float)));
+    g_scr.cap_ypad = n_ypad;
   }
   return TTSX_OK;
 }
 
-unsigned frame_grid(long total) { return (unsigned)std::min<long>(total, 256 * 8); }
+unsigned frame_grid(long total) { return (unsigned)std::min<long>((total + FR_PER_WG - 1) / FR_PER_WG, 256 * 12); }
 
 }  // namespace
 
@@ -428,36 +577,40 @@ extern "C" int ttsx_griffin_lim(const float* mag, const float* init_phase, const
   if (rc) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const float2* tw;
-  const float* win;
-  rc = get_tables(sp, &tw, &win, st);
+  const float* winpad;
+  rc = get_tables(sp, &tw, &winpad);
   if (rc) return rc;
   std::lock_guard<std::mutex> lock(g_scr_mu);
+  const FrameGeom q = make_geom(sp, F);
   const size_t Lmax = (size_t)sp->hop_length * (F - 1);
-  rc = ensure_scratch((size_t)B * F * WP, (size_t)B * Lmax);
+  rc = ensure_scratch((size_t)B * F * WP, (size_t)B * q.LP);
   if (rc) return rc;
   FrameP p{};
-  p.mag = mag, p.phase01 = init_phase, p.n_frames = n_frames, p.tw = tw, p.win = win, p.B = B, p.F = F;
-  p.q = FrameGeom{sp->hop_length, sp->win_length, (NFFT - sp->win_length) / 2, sp->pad_mode};
+  p.mag = mag, p.phase01 = init_phase, p.n_frames = n_frames, p.tw = tw, p.winpad = winpad, p.B = B, p.F = F;
+  p.q = q, p.yw_out = g_scr.yw, p.ypad = g_scr.ypad;
   const unsigned grid = frame_grid((long)B * F);
-  p.yw_out = g_scr.yw[0];
-  frame_kernel<K_GL_INIT><<<grid, FFT_THREADS, 0, st>>>(p);
+  // slots that can hold signal samples: padded indices lpad .. n_fft/2 + Lmax
+  const int n_slots = ceil_div(NFFT / 2 + (int)Lmax - q.lpad, q.hop);
+  const dim3 ola_grid(ceil_div(n_slots, OLA_SLOTS), B), refl_grid(NFFT / 256, B);
+  const bool reflect = sp->pad_mode == TTSX_PAD_REFLECT;
+  frame_kernel<K_GL_INIT><<<grid, 64 * FR_PER_WG, 0, st>>>(p);
   TTSX_LAUNCH_CHECK();
-  int cur = 0;
   for (int it = 0; it < iters; ++it) {
-    p.yw_in = g_scr.yw[cur], p.yw_out = g_scr.yw[cur ^ 1];
-    frame_kernel<K_GL_ITER><<<grid, FFT_THREADS, 0, st>>>(p);
+    ola_kernel<1><<<ola_grid, 320, 0, st>>>(g_scr.ypad, g_scr.yw, winpad, n_frames, B, F, q, n_slots);
+    if (reflect) reflect_pad_kernel<<<refl_grid, 256, 0, st>>>(g_scr.ypad, n_frames, B, F, q);
+    frame_kernel<K_GL_ITER><<<grid, 64 * FR_PER_WG, 0, st>>>(p);
     TTSX_LAUNCH_CHECK();
-    cur ^= 1;
   }
-  const bool de = preemph != 0.f;
-  ola_kernel<<<dim3((unsigned)((Lmax + 255) / 256), B), 256, 0, st>>>(de ? g_scr.y : wav, g_scr.yw[cur], win, n_frames,
-                                                                    B, F, p.q);
-  TTSX_LAUNCH_CHECK();
-  if (de) {
+  if (preemph != 0.f) {
+    // final overlap-add into the padded buffer, then the IIR reads the trimmed part of it
+    ola_kernel<1><<<ola_grid, 320, 0, st>>>(g_scr.ypad, g_scr.yw, winpad, n_frames, B, F, q, n_slots);
     const int nseg = (int)((Lmax + DE_SEG - 1) / DE_SEG);
-    deemph_kernel<<<dim3(ceil_div(nseg, 64), B), 64, 0, st>>>(wav, g_scr.y, n_frames, B, F, sp->hop_length, preemph);
-    TTSX_LAUNCH_CHECK();
+    deemph_kernel<<<dim3(ceil_div(nseg, 64), B), 64, 0, st>>>(wav, g_scr.ypad + NFFT / 2, (size_t)q.LP, n_frames, B, F,
+                                                            sp->hop_length, preemph);
+  } else {
+    ola_kernel<0><<<ola_grid, 320, 0, st>>>(wav, g_scr.yw, winpad, n_frames, B, F, q, n_slots);
   }
+  TTSX_LAUNCH_CHECK();
   // the scratch is shared by every call in the process: finish before releasing the lock
   TTSX_HIP(hipStreamSynchronize(st));
   return TTSX_OK;
@@ -470,14 +623,21 @@ extern "C" int ttsx_stft(const float* y, int B, int F, const ttsx_stft_params* s
   if (rc) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const float2* tw;
-  const float* win;
-  rc = get_tables(sp, &tw, &win, st);
+  const float* winpad;
+  rc = get_tables(sp, &tw, &winpad);
   if (rc) return rc;
-  FrameP p{};
-  p.y_in = y, p.spec_re = spec_re, p.spec_im = spec_im, p.tw = tw, p.win = win, p.B = B, p.F = F;
-  p.q = FrameGeom{sp->hop_length, sp->win_length, (NFFT - sp->win_length) / 2, sp->pad_mode};
-  frame_kernel<K_STFT><<<frame_grid((long)B * F), FFT_THREADS, 0, st>>>(p);
+  std::lock_guard<std::mutex> lock(g_scr_mu);
+  const FrameGeom q = make_geom(sp, F);
+  rc = ensure_scratch(0, (size_t)B * q.LP);
+  if (rc) return rc;
+  pad_signal_kernel<<<dim3((unsigned)((q.LP + 255) / 256), B), 256, 0, st>>>(g_scr.ypad, y, B, F, q);
   TTSX_LAUNCH_CHECK();
+  FrameP p{};
+  p.ypad = g_scr.ypad, p.spec_re = spec_re, p.spec_im = spec_im, p.tw = tw, p.winpad = winpad, p.B = B, p.F = F;
+  p.q = q;
+  frame_kernel<K_STFT><<<frame_grid((long)B * F), 64 * FR_PER_WG, 0, st>>>(p);
+  TTSX_LAUNCH_CHECK();
+  TTSX_HIP(hipStreamSynchronize(st));
   return TTSX_OK;
 }
 
@@ -488,20 +648,21 @@ extern "C" int ttsx_istft(const float* spec_re, const float* spec_im, int B, int
   if (rc) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const float2* tw;
-  const float* win;
-  rc = get_tables(sp, &tw, &win, st);
+  const float* winpad;
+  rc = get_tables(sp, &tw, &winpad);
   if (rc) return rc;
   std::lock_guard<std::mutex> lock(g_scr_mu);
+  const FrameGeom q = make_geom(sp, F);
   const size_t Lmax = (size_t)sp->hop_length * (F - 1);
   rc = ensure_scratch((size_t)B * F * WP, 0);
   if (rc) return rc;
   FrameP p{};
-  p.spec_re = const_cast<float*>(spec_re), p.spec_im = const_cast<float*>(spec_im), p.tw = tw, p.win = win;
-  p.B = B, p.F = F, p.yw_out = g_scr.yw[0];
-  p.q = FrameGeom{sp->hop_length, sp->win_length, (NFFT - sp->win_length) / 2, sp->pad_mode};
-  frame_kernel<K_ISTFT><<<frame_grid((long)B * F), FFT_THREADS, 0, st>>>(p);
+  p.spec_re = const_cast<float*>(spec_re), p.spec_im = const_cast<float*>(spec_im), p.tw = tw, p.winpad = winpad;
+  p.B = B, p.F = F, p.yw_out = g_scr.yw, p.q = q;
+  frame_kernel<K_ISTFT><<<frame_grid((long)B * F), 64 * FR_PER_WG, 0, st>>>(p);
   TTSX_LAUNCH_CHECK();
-  ola_kernel<<<dim3((unsigned)((Lmax + 255) / 256), B), 256, 0, st>>>(y, g_scr.yw[0], win, nullptr, B, F, p.q);
+  const int n_slots = ceil_div(NFFT / 2 + (int)Lmax - q.lpad, q.hop);
+  ola_kernel<0><<<dim3(ceil_div(n_slots, OLA_SLOTS), B), 320, 0, st>>>(y, g_scr.yw, winpad, nullptr, B, F, q, n_slots);
   TTSX_LAUNCH_CHECK();
   TTSX_HIP(hipStreamSynchronize(st));
   return TTSX_OK;

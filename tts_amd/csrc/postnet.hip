@@ -1,9 +1,9 @@
-// Tacotron2 postnet for gfx950: five k=5 convolutions as implicit GEMMs on the fp32 MFMA
-// (v_mfma_f32_32x32x2_f32), eval-mode BatchNorm folded into the weights, tanh fused into the
-// epilogue, residual add fused into the last layer.
+// Tacotron2 ConvBNBlock stacks for gfx950: k=5 convolutions as implicit GEMMs on the fp32 MFMA
+// (v_mfma_f32_32x32x2_f32), eval-mode BatchNorm folded into the weights, tanh / ReLU fused into
+// the epilogue, residual add fused into the last postnet layer.
 //
-// Follows Postnet.forward and the residual of Tacotron2.inference
-// (Tacotron2/TTS/models.py:402-417, 380-400, 809-810).
+// Follows ConvBNBlock (Tacotron2/TTS/models.py:380-400) as used by Postnet.forward with the
+// residual of Tacotron2.inference (:402-417, 809-810) and by Encoder.inference (:449-451).
 //
 // Layout.  Activations are frame-major [B][F][C] (what Tacotron2.inference returns), so the
 // K axis of the implicit GEMM, ordered tap-major (k = tap*Cin + ci), is contiguous in memory
@@ -11,6 +11,8 @@
 // 16-byte load per lane, no im2col and no LDS staging.  Weights are packed per 32-row block
 // and per 8-wide K chunk as 64 lanes x 4 floats in A-operand order (lane l: row l&31,
 // k = 4*(l>>5) + s for issue s), so a wave streams them with coalesced 1 KiB loads.
+#include <algorithm>
+
 #include "common.h"
 
 namespace {
@@ -53,7 +55,7 @@ struct ConvP {
   float* y;              // [B][F][Cout]
   const float* residual; // [B][F][Cout] or null
   const int32_t* n_frames;
-  int B, F, Cin, Cout, NC, act_tanh;
+  int B, F, Cin, Cout, NC, act;  // act: 0 none, 1 tanh, 2 relu
 };
 
 // Block = 4 waves as 2 (Cout) x 2 (frames); each wave owns a 64 x 64 output tile held as
@@ -135,7 +137,8 @@ __global__ __launch_bounds__(256) void conv5_mfma_kernel(ConvP p) {
         const float4 bv = *reinterpret_cast<const float4*>(p.bias + co);
         float4 v = make_float4(acc[i][j][4 * g] + bv.x, acc[i][j][4 * g + 1] + bv.y, acc[i][j][4 * g + 2] + bv.z,
                                acc[i][j][4 * g + 3] + bv.w);
-        if (p.act_tanh) v = make_float4(tanhf(v.x), tanhf(v.y), tanhf(v.z), tanhf(v.w));
+        if (p.act == 1) v = make_float4(tanhf(v.x), tanhf(v.y), tanhf(v.z), tanhf(v.w));
+        else if (p.act == 2) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
         if (p.residual) {
           const float4 rv = *reinterpret_cast<const float4*>(p.residual + obase + co);
           v.x += rv.x, v.y += rv.y, v.z += rv.z, v.w += rv.w;
@@ -148,45 +151,108 @@ __global__ __launch_bounds__(256) void conv5_mfma_kernel(ConvP p) {
 
 }  // namespace
 
-struct ttsx_postnet {
-  float* wp[5];
-  float* bias[5];
-  int cin[5], cout[5];
+constexpr int MAX_LAYERS = 8;
+struct ConvStack {
+  int n;
+  float* wp[MAX_LAYERS];
+  float* bias[MAX_LAYERS];
+  int cin[MAX_LAYERS], cout[MAX_LAYERS], act[MAX_LAYERS];
+  bool residual_last;
   float* buf[2];
   size_t buf_cap;
 };
 
-extern "C" int ttsx_postnet_create(const ttsx_postnet_weights* w, void* stream, ttsx_postnet** out) {
-  TTSX_ARG(w && out, "ttsx_postnet_create: null argument");
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  ttsx_postnet* p = new ttsx_postnet();
+namespace {
+
+int stack_create(ConvStack* p, int n, const int* chans, const int* acts, bool residual_last,
+                 const float* const* conv_w, const float* const* conv_b, const float* const* bn_w,
+                 const float* const* bn_b, const float* const* bn_m, const float* const* bn_v, hipStream_t st) {
   memset(p, 0, sizeof(*p));
-  const int chans[6] = {80, 512, 512, 512, 512, 80};
-  for (int i = 0; i < 5; ++i) {
+  p->n = n, p->residual_last = residual_last;
+  for (int i = 0; i < n; ++i) {
     const int cin = chans[i], cout = chans[i + 1];
-    p->cin[i] = cin, p->cout[i] = cout;
+    TTSX_ARG(cin % 8 == 0 && cout % 4 == 0, "conv stack: channel counts %d -> %d unsupported", cin, cout);
+    TTSX_ARG(conv_w[i] && conv_b[i] && bn_w[i] && bn_b[i] && bn_m[i] && bn_v[i], "conv stack: null weight (layer %d)", i);
+    p->cin[i] = cin, p->cout[i] = cout, p->act[i] = acts[i];
     const int NC = TAPS * cin / 8;
-    const size_t n = (size_t)ceil_div(cout, 32) * NC * 256;
-    TTSX_HIP(hipMalloc(reinterpret_cast<void**>(&p->wp[i]), n * sizeof(float)));
+    const size_t nw = (size_t)ceil_div(cout, 32) * NC * 256;
+    TTSX_HIP(hipMalloc(reinterpret_cast<void**>(&p->wp[i]), nw * sizeof(float)));
     TTSX_HIP(hipMalloc(reinterpret_cast<void**>(&p->bias[i]), round_up(cout, 32) * sizeof(float)));
-    pack_conv_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(p->wp[i], p->bias[i], w->conv_w[i], w->conv_b[i],
-                                                                 w->bn_weight[i], w->bn_bias[i], w->bn_mean[i],
-                                                                 w->bn_var[i], cout, cin);
+    pack_conv_kernel<<<(unsigned)((nw + 255) / 256), 256, 0, st>>>(p->wp[i], p->bias[i], conv_w[i], conv_b[i], bn_w[i],
+                                                                  bn_b[i], bn_m[i], bn_v[i], cout, cin);
     TTSX_LAUNCH_CHECK();
   }
   TTSX_HIP(hipStreamSynchronize(st));
+  return TTSX_OK;
+}
+
+void stack_destroy(ConvStack* p) {
+  for (int i = 0; i < p->n; ++i) {
+    if (p->wp[i]) (void)hipFree(p->wp[i]);
+    if (p->bias[i]) (void)hipFree(p->bias[i]);
+  }
+  for (int i = 0; i < 2; ++i)
+    if (p->buf[i]) (void)hipFree(p->buf[i]);
+}
+
+int stack_run(ConvStack* p, const float* in, const int32_t* n_frames, int B, int F, float* out, hipStream_t st) {
+  int cmax = 0;
+  for (int i = 0; i < p->n; ++i) cmax = std::max(cmax, p->cout[i]);
+  const size_t need = (size_t)B * F * cmax;
+  if (need > p->buf_cap) {
+    for (int i = 0; i < 2; ++i) {
+      if (p->buf[i]) (void)hipFree(p->buf[i]);
+      p->buf[i] = nullptr;
+      p->buf_cap = 0;
+      TTSX_HIP(hipMalloc(reinterpret_cast<void**>(&p->buf[i]), need * sizeof(float)));
+    }
+    p->buf_cap = need;
+  }
+  const float* x = in;
+  for (int i = 0; i < p->n; ++i) {
+    const bool last = i == p->n - 1;
+    ConvP c{};
+    c.wp = p->wp[i], c.bias = p->bias[i], c.x = x, c.n_frames = n_frames;
+    c.y = last ? out : p->buf[i & 1];
+    c.residual = (last && p->residual_last) ? in : nullptr;
+    c.B = B, c.F = F, c.Cin = p->cin[i], c.Cout = p->cout[i], c.NC = TAPS * p->cin[i] / 8, c.act = p->act[i];
+    const long ncols = (long)B * F;
+    dim3 grid((unsigned)((ncols + 127) / 128), ceil_div(c.Cout, 128));
+    conv5_mfma_kernel<<<grid, 256, 0, st>>>(c);
+    TTSX_LAUNCH_CHECK();
+    x = c.y;
+  }
+  return TTSX_OK;
+}
+
+}  // namespace
+
+struct ttsx_postnet {
+  ConvStack st;
+};
+struct ttsx_encoder_convs {
+  ConvStack st;
+};
+
+extern "C" int ttsx_postnet_create(const ttsx_postnet_weights* w, void* stream, ttsx_postnet** out) {
+  TTSX_ARG(w && out, "ttsx_postnet_create: null argument");
+  ttsx_postnet* p = new ttsx_postnet();
+  const int chans[6] = {80, 512, 512, 512, 512, 80};
+  const int acts[5] = {1, 1, 1, 1, 0};
+  int rc = stack_create(&p->st, 5, chans, acts, true, w->conv_w, w->conv_b, w->bn_weight, w->bn_bias, w->bn_mean,
+                        w->bn_var, static_cast<hipStream_t>(stream));
+  if (rc) {
+    stack_destroy(&p->st);
+    delete p;
+    return rc;
+  }
   *out = p;
   return TTSX_OK;
 }
 
 extern "C" int ttsx_postnet_destroy(ttsx_postnet* p) {
   if (!p) return TTSX_OK;
-  for (int i = 0; i < 5; ++i) {
-    if (p->wp[i]) (void)hipFree(p->wp[i]);
-    if (p->bias[i]) (void)hipFree(p->bias[i]);
-  }
-  for (int i = 0; i < 2; ++i)
-    if (p->buf[i]) (void)hipFree(p->buf[i]);
+  stack_destroy(&p->st);
   delete p;
   return TTSX_OK;
 }
@@ -195,28 +261,35 @@ extern "C" int ttsx_postnet_run(ttsx_postnet* p, const float* mel, const int32_t
                                 void* stream) {
   TTSX_ARG(p && mel && out, "ttsx_postnet_run: null argument");
   TTSX_ARG(B >= 1 && F >= 1, "ttsx_postnet_run: bad shape B=%d F=%d", B, F);
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  const size_t need = (size_t)B * F * 512;
-  if (need > p->buf_cap) {
-    for (int i = 0; i < 2; ++i) {
-      if (p->buf[i]) (void)hipFree(p->buf[i]);
-      p->buf[i] = nullptr;
-      TTSX_HIP(hipMalloc(reinterpret_cast<void**>(&p->buf[i]), need * sizeof(float)));
-    }
-    p->buf_cap = need;
+  return stack_run(&p->st, mel, n_frames, B, F, out, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int ttsx_encoder_convs_create(const ttsx_encoder_conv_weights* w, void* stream, ttsx_encoder_convs** out) {
+  TTSX_ARG(w && out, "ttsx_encoder_convs_create: null argument");
+  ttsx_encoder_convs* p = new ttsx_encoder_convs();
+  const int chans[4] = {512, 512, 512, 512};
+  const int acts[3] = {2, 2, 2};
+  int rc = stack_create(&p->st, 3, chans, acts, false, w->conv_w, w->conv_b, w->bn_weight, w->bn_bias, w->bn_mean,
+                        w->bn_var, static_cast<hipStream_t>(stream));
+  if (rc) {
+    stack_destroy(&p->st);
+    delete p;
+    return rc;
   }
-  const float* x = mel;
-  for (int i = 0; i < 5; ++i) {
-    ConvP c{};
-    c.wp = p->wp[i], c.bias = p->bias[i], c.x = x, c.n_frames = n_frames;
-    c.y = i == 4 ? out : p->buf[i & 1];
-    c.residual = i == 4 ? mel : nullptr;
-    c.B = B, c.F = F, c.Cin = p->cin[i], c.Cout = p->cout[i], c.NC = TAPS * p->cin[i] / 8, c.act_tanh = i < 4;
-    const long ncols = (long)B * F;
-    dim3 grid((unsigned)((ncols + 127) / 128), ceil_div(c.Cout, 128));
-    conv5_mfma_kernel<<<grid, 256, 0, st>>>(c);
-    TTSX_LAUNCH_CHECK();
-    x = c.y;
-  }
+  *out = p;
   return TTSX_OK;
+}
+
+extern "C" int ttsx_encoder_convs_destroy(ttsx_encoder_convs* p) {
+  if (!p) return TTSX_OK;
+  stack_destroy(&p->st);
+  delete p;
+  return TTSX_OK;
+}
+
+extern "C" int ttsx_encoder_convs_run(ttsx_encoder_convs* p, const float* x, const int32_t* lengths, int B, int T,
+                                      float* out, void* stream) {
+  TTSX_ARG(p && x && out, "ttsx_encoder_convs_run: null argument");
+  TTSX_ARG(B >= 1 && T >= 1, "ttsx_encoder_convs_run: bad shape B=%d T=%d", B, T);
+  return stack_run(&p->st, x, lengths, B, T, out, static_cast<hipStream_t>(stream));
 }

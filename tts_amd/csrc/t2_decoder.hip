@@ -222,59 +222,60 @@ __device__ inline const float* seg_ptr(const Seg& sg, int step) {
 }
 
 // fp32 MFMA engine: one row block x NT column tiles of 16 utterances per workgroup, the K axis
-// split over the 8 waves, partial tiles combined through LDS.
-template <int NT, int MODE>
+// split over the 8 waves (wave w takes k-groups w, w+8, ...), partial tiles combined through LDS.
+// KGW = k-groups per wave.  The k-loop is fully unrolled and software-pipelined: the loads of
+// k-group i+D are issued before the MFMAs of k-group i, so D groups (weights from HBM, activations
+// from L2) are always in flight per wave.
+template <int NT, int KGW, int MODE>
 __global__ __launch_bounds__(GEMM_THREADS) void rowblock_gemm_kernel(GemmP p) {
   if (p.ctx->all_done) return;
   const int step = p.ctx->base + p.step_in_chunk;
   const int rb = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int b0 = blockIdx.y * (NT * 16);
+  constexpr int KG = KGW * GEMM_WAVES;
+  constexpr int D = KGW < (NT == 1 ? 8 : 6) ? KGW : (NT == 1 ? 8 : 6);
   __shared__ f32x4 red[GEMM_WAVES][NT][64];
 
   f32x4 acc[NT];
 #pragma unroll
   for (int n = 0; n < NT; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const float4* W = reinterpret_cast<const float4*>(p.Wp) + (size_t)rb * p.KG * 64 + lane;
-  const int col = b0 + (lane & 15);
-  const int kq = lane >> 4;
-  constexpr int U = NT >= 3 ? 2 : 4;  // k-groups whose loads are issued together
-  int kg_base = 0;
-  for (int s = 0; s < p.nseg; ++s) {
-    const Seg sg = p.seg[s];
-    const float4* X = reinterpret_cast<const float4*>(seg_ptr(sg, step)) + (size_t)kq * p.Bpad + col;
-    const size_t xs = (size_t)4 * p.Bpad;
-    int kg = wave;
-    for (; kg + (U - 1) * GEMM_WAVES < sg.kgroups; kg += U * GEMM_WAVES) {
-      float4 wv[U], xv[U][NT];
+  const float4* W = reinterpret_cast<const float4*>(p.Wp) + ((size_t)rb * KG + wave) * 64 + lane;
+  // activation pointers of the (up to three) segments, positioned at this lane's quad row / column
+  const size_t xoff = (size_t)(lane >> 4) * p.Bpad + b0 + (lane & 15);
+  const float4* X0 = reinterpret_cast<const float4*>(seg_ptr(p.seg[0], step)) + xoff;
+  const float4* X1 = p.nseg > 1 ? reinterpret_cast<const float4*>(seg_ptr(p.seg[1], step)) + xoff : X0;
+  const float4* X2 = p.nseg > 2 ? reinterpret_cast<const float4*>(seg_ptr(p.seg[2], step)) + xoff : X0;
+  const int e0 = p.seg[0].kgroups, e1 = e0 + (p.nseg > 1 ? p.seg[1].kgroups : 0);
+  const size_t xs = (size_t)4 * p.Bpad;  // float4 stride between k-groups
+  auto xptr = [&](int g) -> const float4* {
+    return g < e0 ? X0 + (size_t)g * xs : (g < e1 ? X1 + (size_t)(g - e0) * xs : X2 + (size_t)(g - e1) * xs);
+  };
+
+  float4 wv[D], xv[D][NT];
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        wv[u] = W[(size_t)(kg_base + kg + u * GEMM_WAVES) * 64];
+  for (int i = 0; i < D; ++i) {
+    wv[i] = W[(size_t)i * GEMM_WAVES * 64];
+    const float4* xp = xptr(wave + i * GEMM_WAVES);
 #pragma unroll
-        for (int n = 0; n < NT; ++n) xv[u][n] = X[(size_t)(kg + u * GEMM_WAVES) * xs + n * 16];
-      }
+    for (int n = 0; n < NT; ++n) xv[i][n] = xp[n * 16];
+  }
 #pragma unroll
-      for (int u = 0; u < U; ++u)
+  for (int i = 0; i < KGW; ++i) {
+    const int sl = i % D;
 #pragma unroll
-        for (int n = 0; n < NT; ++n) {
-          acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[u].x, xv[u][n].x, acc[n], 0, 0, 0);
-          acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[u].y, xv[u][n].y, acc[n], 0, 0, 0);
-          acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[u].z, xv[u][n].z, acc[n], 0, 0, 0);
-          acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[u].w, xv[u][n].w, acc[n], 0, 0, 0);
-        }
+    for (int n = 0; n < NT; ++n) {
+      acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[sl].x, xv[sl][n].x, acc[n], 0, 0, 0);
+      acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[sl].y, xv[sl][n].y, acc[n], 0, 0, 0);
+      acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[sl].z, xv[sl][n].z, acc[n], 0, 0, 0);
+      acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[sl].w, xv[sl][n].w, acc[n], 0, 0, 0);
     }
-    for (; kg < sg.kgroups; kg += GEMM_WAVES) {
-      const float4 wv = W[(size_t)(kg_base + kg) * 64];
+    if (i + D < KGW) {
+      wv[sl] = W[(size_t)(i + D) * GEMM_WAVES * 64];
+      const float4* xp = xptr(wave + (i + D) * GEMM_WAVES);
 #pragma unroll
-      for (int n = 0; n < NT; ++n) {
-        const float4 xv = X[(size_t)kg * xs + n * 16];
-        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.x, xv.x, acc[n], 0, 0, 0);
-        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.y, xv.y, acc[n], 0, 0, 0);
-        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.z, xv.z, acc[n], 0, 0, 0);
-        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.w, xv.w, acc[n], 0, 0, 0);
-      }
+      for (int n = 0; n < NT; ++n) xv[sl][n] = xp[n * 16];
     }
-    kg_base += sg.kgroups;
   }
 #pragma unroll
   for (int n = 0; n < NT; ++n) red[wave][n][lane] = acc[n];
@@ -371,8 +372,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void rowblock_gemv_kernel(GemmP p) {
 struct AttnP {
   const float* q;        // quad [128]
   const float* P;        // [B][T][128]  processed_inputs
-  const float* loc_conv_w;   // [32][2][31]
-  const float* loc_dense_w;  // [128][32]
+  const float* loc_conv_t;   // [2*31][32]   location_conv weight, filter index fastest
+  const float* loc_dense_t;  // [8][128][4]  location_dense weight: quad of filters x dim, dim fastest
   const float* v_w;          // [128]
   const float* v_b;          // [1]
   float* a_prev;         // [B][T]
@@ -385,31 +386,58 @@ struct AttnP {
 
 constexpr int EN_TT = 32, EN_THREADS = 512, ATT_PAD = (LOC_K - 1) / 2;
 
+// tanh through one hardware exponential: 1 - 2/(e^{2x}+1); saturates correctly at +-inf
+__device__ __forceinline__ float fast_tanhf(float x) {
+  const float t = __expf(2.f * x);
+  return 1.f - 2.f * __builtin_amdgcn_rcpf(t + 1.f);
+}
+
 // energies e[b][t] for a tile of 32 encoder positions:
 //   cf[t][f] = sum_{c,j} W_lc[f][c][j] * a_c[t + j - 15]         (thread: filter f, 2 positions)
 //   e[t] = b_v + sum_d v[d] * tanh(q[d] + sum_f W_ld[d][f] cf[t][f] + P[t][d])   (thread: dim d, 8 positions)
+// Every global load of the kernel is issued before the first barrier, so the whole kernel costs
+// one memory round trip.
 __global__ __launch_bounds__(EN_THREADS) void energy_kernel(AttnP p) {
   const RunCtx* cx = p.ctx;
   if (cx->all_done) return;
   const int T = cx->T, b = blockIdx.y, t0 = blockIdx.x * EN_TT, tid = threadIdx.x;
   __shared__ float s_a[2][EN_TT + 2 * ATT_PAD + 2];
   __shared__ __attribute__((aligned(16))) float s_cf[EN_TT][LOC_F];
-  __shared__ float s_q[ATT_DIM];
   __shared__ float s_part[2][EN_TT];
 
+  // ---- loads: alignment window (124 threads), conv weights, dense weights, P, q, v
+  float a_in = 0.f;
   if (tid < 2 * (EN_TT + 2 * ATT_PAD)) {
     const int c = tid / (EN_TT + 2 * ATT_PAD), i = tid % (EN_TT + 2 * ATT_PAD);
     const int t = t0 + i - ATT_PAD;
     const float* src = c == 0 ? p.a_prev : p.a_cum;
-    s_a[c][i] = (t >= 0 && t < T) ? src[(size_t)b * T + t] : 0.f;
-  } else if (tid >= 256 && tid < 256 + ATT_DIM) {
-    s_q[tid - 256] = p.q[qidx(tid - 256, b, p.Bpad)];
+    if (t >= 0 && t < T) a_in = src[(size_t)b * T + t];
   }
+  const int f = tid & 31, tp = tid >> 5;  // conv role: filter f, positions 2 tp, 2 tp + 1
+  float wl[2 * LOC_K];
+#pragma unroll
+  for (int j = 0; j < 2 * LOC_K; ++j) wl[j] = p.loc_conv_t[j * LOC_F + f];
+  const int d = tid & 127, tg = tid >> 7;  // dense role: dim d, positions tg*8 .. tg*8+7
+  float wd[LOC_F];
+  {
+    const float4* wsrc = reinterpret_cast<const float4*>(p.loc_dense_t) + d;
+#pragma unroll
+    for (int i = 0; i < LOC_F / 4; ++i) {
+      const float4 t4 = wsrc[i * ATT_DIM];
+      wd[4 * i] = t4.x, wd[4 * i + 1] = t4.y, wd[4 * i + 2] = t4.z, wd[4 * i + 3] = t4.w;
+    }
+  }
+  float pin[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int t = t0 + tg * 8 + i;
+    pin[i] = t < T ? p.P[((size_t)b * T + t) * ATT_DIM + d] : 0.f;
+  }
+  const float qd = p.q[qidx(d, b, p.Bpad)], vd = p.v_w[d], vb = p.v_b[0];
+
+  if (tid < 2 * (EN_TT + 2 * ATT_PAD)) s_a[tid / (EN_TT + 2 * ATT_PAD)][tid % (EN_TT + 2 * ATT_PAD)] = a_in;
   __syncthreads();
   {
-    // location conv: filter f, positions tp*2, tp*2+1
-    const int f = tid & 31, tp = tid >> 5;  // tp 0..15
-    const float* w = p.loc_conv_w + f * 2 * LOC_K;
     float acc0 = 0.f, acc1 = 0.f;
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
@@ -418,53 +446,37 @@ __global__ __launch_bounds__(EN_THREADS) void energy_kernel(AttnP p) {
       for (int j = 0; j < LOC_K + 1; ++j) win[j] = s_a[c][tp * 2 + j];
 #pragma unroll
       for (int j = 0; j < LOC_K; ++j) {
-        const float wj = w[c * LOC_K + j];
-        acc0 += wj * win[j];
-        acc1 += wj * win[j + 1];
+        acc0 += wl[c * LOC_K + j] * win[j];
+        acc1 += wl[c * LOC_K + j] * win[j + 1];
       }
     }
     s_cf[tp * 2][f] = acc0;
     s_cf[tp * 2 + 1][f] = acc1;
   }
   __syncthreads();
-  {
-    const int d = tid & 127, tg = tid >> 7;  // tg 0..3 -> positions tg*8 .. tg*8+7
-    float wd[LOC_F];
-    const float4* wsrc = reinterpret_cast<const float4*>(p.loc_dense_w + d * LOC_F);
 #pragma unroll
-    for (int i = 0; i < LOC_F / 4; ++i) {
-      const float4 t4 = wsrc[i];
-      wd[4 * i] = t4.x, wd[4 * i + 1] = t4.y, wd[4 * i + 2] = t4.z, wd[4 * i + 3] = t4.w;
+  for (int i = 0; i < 8; ++i) {
+    const int tl = tg * 8 + i;
+    const float4* cf4 = reinterpret_cast<const float4*>(&s_cf[tl][0]);
+    float loc = 0.f;
+#pragma unroll
+    for (int k = 0; k < LOC_F / 4; ++k) {
+      const float4 c4 = cf4[k];
+      loc += wd[4 * k] * c4.x + wd[4 * k + 1] * c4.y + wd[4 * k + 2] * c4.z + wd[4 * k + 3] * c4.w;
     }
-    const float qd = s_q[d], vd = p.v_w[d];
-    float pin[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int t = t0 + tg * 8 + i;
-      pin[i] = t < T ? p.P[((size_t)b * T + t) * ATT_DIM + d] : 0.f;
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int tl = tg * 8 + i;
-      const float4* cf4 = reinterpret_cast<const float4*>(&s_cf[tl][0]);
-      float loc = 0.f;
-#pragma unroll
-      for (int k = 0; k < LOC_F / 4; ++k) {
-        const float4 c4 = cf4[k];
-        loc += wd[4 * k] * c4.x + wd[4 * k + 1] * c4.y + wd[4 * k + 2] * c4.z + wd[4 * k + 3] * c4.w;
-      }
-      float e = vd * tanhf(qd + loc + pin[i]);
-      e = wave_sum(e);
-      if ((tid & 63) == 0) s_part[(tid >> 6) & 1][tl] = e;
-    }
+    float e = vd * fast_tanhf(qd + loc + pin[i]);
+    e = wave_sum(e);
+    if ((tid & 63) == 0) s_part[(tid >> 6) & 1][tl] = e;
   }
   __syncthreads();
-  if (tid < EN_TT && t0 + tid < T) p.energies[(size_t)b * T + t0 + tid] = s_part[0][tid] + s_part[1][tid] + p.v_b[0];
+  if (tid < EN_TT && t0 + tid < T) p.energies[(size_t)b * T + t0 + tid] = s_part[0][tid] + s_part[1][tid] + vb;
 }
 
 // normalisation over the encoder axis (every workgroup of an utterance repeats it: T exps) and a
 // slice of CW context columns: ctx[c] = sum_t a[t] enc[t][c].  Workgroup x == 0 also writes the
-// alignment outputs and the location-attention state.
+// alignment outputs and the location-attention state.  The first CTX_PRE rows of encoder outputs
+// a thread needs are loaded before the normalisation, so that round trip overlaps it.
+constexpr int CTX_PRE = 16;
 template <int CW>
 __global__ __launch_bounds__(256) void context_kernel(AttnP p) {
   RunCtx* cx = p.ctx;
@@ -475,6 +487,17 @@ __global__ __launch_bounds__(256) void context_kernel(AttnP p) {
   float* s_al = s_dyn;  // [T]
   __shared__ float s_red[4];
   __shared__ float4 s_acc[256];
+
+  // context slice geometry: lane group = CW/4 float4 columns, row groups stride over t
+  constexpr int LPR = CW / 4, RG = 256 / LPR;
+  const int cl = tid % LPR, rg = tid / LPR;
+  const float4* e4 = reinterpret_cast<const float4*>(cx->enc + (size_t)b * T * ENC_DIM + blockIdx.x * CW) + cl;
+  float4 pre[CTX_PRE];
+#pragma unroll
+  for (int i = 0; i < CTX_PRE; ++i) {
+    const int t = rg + i * RG;
+    pre[i] = t < len ? e4[(size_t)t * (ENC_DIM / 4)] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
 
   const bool softmax = p.norm == TTSX_NORM_SOFTMAX;
   float m = -INFINITY;
@@ -512,22 +535,14 @@ __global__ __launch_bounds__(256) void context_kernel(AttnP p) {
       cx->align[((size_t)b * cx->align_rows + row) * T + t] = a;
     }
   }
-  // context slice: lane group = CW/4 float4 columns, row groups stride over t
-  constexpr int LPR = CW / 4, RG = 256 / LPR;
-  const int cl = tid % LPR, rg = tid / LPR;
-  const float4* e4 = reinterpret_cast<const float4*>(cx->enc + (size_t)b * T * ENC_DIM + blockIdx.x * CW) + cl;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  int t = rg;
-  for (; t + 3 * RG < len; t += 4 * RG) {
-    const float4 v0 = e4[(size_t)t * (ENC_DIM / 4)], v1 = e4[(size_t)(t + RG) * (ENC_DIM / 4)];
-    const float4 v2 = e4[(size_t)(t + 2 * RG) * (ENC_DIM / 4)], v3 = e4[(size_t)(t + 3 * RG) * (ENC_DIM / 4)];
-    const float a0 = s_al[t], a1 = s_al[t + RG], a2 = s_al[t + 2 * RG], a3 = s_al[t + 3 * RG];
-    acc.x += a0 * v0.x + a1 * v1.x + a2 * v2.x + a3 * v3.x;
-    acc.y += a0 * v0.y + a1 * v1.y + a2 * v2.y + a3 * v3.y;
-    acc.z += a0 * v0.z + a1 * v1.z + a2 * v2.z + a3 * v3.z;
-    acc.w += a0 * v0.w + a1 * v1.w + a2 * v2.w + a3 * v3.w;
+#pragma unroll
+  for (int i = 0; i < CTX_PRE; ++i) {
+    const int t = rg + i * RG;
+    const float a0 = t < len ? s_al[t] : 0.f;
+    acc.x += a0 * pre[i].x, acc.y += a0 * pre[i].y, acc.z += a0 * pre[i].z, acc.w += a0 * pre[i].w;
   }
-  for (; t < len; t += RG) {
+  for (int t = rg + CTX_PRE * RG; t < len; t += RG) {
     const float4 v0 = e4[(size_t)t * (ENC_DIM / 4)];
     const float a0 = s_al[t];
     acc.x += a0 * v0.x, acc.y += a0 * v0.y, acc.z += a0 * v0.z, acc.w += a0 * v0.w;
@@ -576,6 +591,20 @@ __global__ __launch_bounds__(256) void inputs_proj_kernel(float* __restrict__ P,
   for (int i = 0; i < 8; ++i) {
     const int t = t0 + tg * 8 + i;
     if (t < T) P[((size_t)b * T + t) * ATT_DIM + d] = acc[i];
+  }
+}
+
+// location-layer weights in the orders the energy kernel reads them coalesced
+__global__ void transpose_loc_kernel(float* __restrict__ conv_t, float* __restrict__ dense_t,
+                                     const float* __restrict__ conv_w, const float* __restrict__ dense_w) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < LOC_F * 2 * LOC_K) {
+    const int f = i / (2 * LOC_K), j = i % (2 * LOC_K);
+    conv_t[j * LOC_F + f] = conv_w[i];
+  }
+  if (i < ATT_DIM * LOC_F) {
+    const int d = i / LOC_F, f = i % LOC_F;
+    dense_t[((f >> 2) * ATT_DIM + d) * 4 + (f & 3)] = dense_w[i];
   }
 }
 
@@ -761,25 +790,25 @@ int launch_gemm(const ttsx_t2_decoder* d, const GemmP& p, int nrb, bool split_n,
 #undef TTSX_GEMV_NB
 #undef TTSX_GEMV
   } else {
+    // column tiles per workgroup: 2 for the big (weight-streaming) GEMMs when the batch allows,
+    // 1 for the small ones, which need the extra workgroups more than the weight reuse
     const int nt_total = p.Bpad / 16;
-    if (split_n || nt_total > 4) {
-      // small-row GEMMs: one column tile per workgroup for parallelism; or batch > 64
-      if (split_n) {
-        dim3 grid(nrb, nt_total);
-        rowblock_gemm_kernel<1, MODE><<<grid, GEMM_THREADS, 0, st>>>(p);
-      } else {
-        dim3 grid(nrb, p.Bpad / 64);
-        rowblock_gemm_kernel<4, MODE><<<grid, GEMM_THREADS, 0, st>>>(p);
-      }
-    } else {
-      dim3 grid(nrb, 1);
-      switch (nt_total) {
-        case 1: rowblock_gemm_kernel<1, MODE><<<grid, GEMM_THREADS, 0, st>>>(p); break;
-        case 2: rowblock_gemm_kernel<2, MODE><<<grid, GEMM_THREADS, 0, st>>>(p); break;
-        case 3: rowblock_gemm_kernel<3, MODE><<<grid, GEMM_THREADS, 0, st>>>(p); break;
-        default: rowblock_gemm_kernel<4, MODE><<<grid, GEMM_THREADS, 0, st>>>(p); break;
-      }
+    const int nt = (!split_n && nt_total % 2 == 0) ? 2 : 1;
+    dim3 grid(nrb, nt_total / nt);
+#define TTSX_GEMM(KGW)                                                                    \
+  if (nt == 2) rowblock_gemm_kernel<2, KGW, MODE><<<grid, GEMM_THREADS, 0, st>>>(p);      \
+  else rowblock_gemm_kernel<1, KGW, MODE><<<grid, GEMM_THREADS, 0, st>>>(p)
+    switch (p.KG) {
+      case 16: TTSX_GEMM(2); break;
+      case 64: TTSX_GEMM(8); break;
+      case 96: TTSX_GEMM(12); break;
+      case 112: TTSX_GEMM(14); break;
+      case 160: TTSX_GEMM(20); break;
+      default:
+        ttsx_set_error("launch_gemm: no GEMM instance for KG=%d", p.KG);
+        return TTSX_ERR_ARG;
     }
+#undef TTSX_GEMM
   }
   TTSX_LAUNCH_CHECK();
   return TTSX_OK;
@@ -811,7 +840,7 @@ int enqueue_step(ttsx_t2_decoder* d, int i, hipStream_t st) {
   // attention
   AttnP ap{};
   ap.q = d->q, ap.P = d->P;
-  ap.loc_conv_w = d->loc_conv_w, ap.loc_dense_w = d->loc_dense_w, ap.v_w = d->v_w, ap.v_b = d->v_b;
+  ap.loc_conv_t = d->loc_conv_w, ap.loc_dense_t = d->loc_dense_w, ap.v_w = d->v_w, ap.v_b = d->v_b;
   ap.a_prev = d->a_prev, ap.a_cum = d->a_cum, ap.energies = d->energies, ap.ctx_out = d->ctx;
   ap.ctx = d->rc, ap.step_in_chunk = i, ap.Bpad = Bpad, ap.norm = d->norm;
   energy_kernel<<<dim3(ceil_div(T, EN_TT), B), EN_THREADS, 0, st>>>(ap);
@@ -916,9 +945,12 @@ extern "C" int ttsx_t2_decoder_create(const ttsx_t2_decoder_weights* w, int r_in
   rc |= copy_dev(&d->inputs_w, w->inputs_w, ATT_DIM * ENC_DIM, st);
   rc |= copy_dev(&d->v_w, w->v_w, ATT_DIM, st);
   rc |= copy_dev(&d->v_b, w->v_b, 1, st);
-  rc |= copy_dev(&d->loc_conv_w, w->loc_conv_w, LOC_F * 2 * LOC_K, st);
-  rc |= copy_dev(&d->loc_dense_w, w->loc_dense_w, ATT_DIM * LOC_F, st);
+  rc |= dev_alloc(&d->loc_conv_w, LOC_F * 2 * LOC_K);
+  rc |= dev_alloc(&d->loc_dense_w, ATT_DIM * LOC_F);
   if (rc) return TTSX_ERR_HIP;
+  transpose_loc_kernel<<<ceil_div(ATT_DIM * LOC_F, 256), 256, 0, st>>>(d->loc_conv_w, d->loc_dense_w, w->loc_conv_w,
+                                                                      w->loc_dense_w);
+  TTSX_LAUNCH_CHECK();
   TTSX_HIP(hipMalloc(reinterpret_cast<void**>(&d->rc), sizeof(RunCtx)));
   TTSX_HIP(hipMemsetAsync(d->rc, 0, sizeof(RunCtx), st));
   TTSX_HIP(hipHostMalloc(reinterpret_cast<void**>(&d->rc_host), sizeof(RunCtx), hipHostMallocDefault));

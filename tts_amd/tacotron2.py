@@ -73,6 +73,7 @@ class Tacotron2:
         self._sd = None
         self._dec_handle = None
         self._post_handle = None
+        self._enc_handle = None
         self._lstm = None
 
     # ---- torch.nn.Module look-alikes ------------------------------------
@@ -133,6 +134,9 @@ class Tacotron2:
         if self._post_handle is not None:
             _lib.load().ttsx_postnet_destroy(self._post_handle)
             self._post_handle = None
+        if self._enc_handle is not None:
+            _lib.load().ttsx_encoder_convs_destroy(self._enc_handle)
+            self._enc_handle = None
 
     def _upload(self):
         lib = _lib.load()
@@ -178,6 +182,16 @@ class Tacotron2:
             _lib.check(lib.ttsx_postnet_create(ctypes.byref(pw), _lib.current_stream(), ctypes.byref(ph)),
                        "ttsx_postnet_create")
             self._post_handle = ph
+            ew = _lib.EncoderConvWeights()
+            for i in range(3):
+                p = "encoder.convolutions.%d.net." % i
+                ew.conv_w[i], ew.conv_b[i] = sd[p + "0.weight"].data_ptr(), sd[p + "0.bias"].data_ptr()
+                ew.bn_weight[i], ew.bn_bias[i] = sd[p + "1.weight"].data_ptr(), sd[p + "1.bias"].data_ptr()
+                ew.bn_mean[i], ew.bn_var[i] = sd[p + "1.running_mean"].data_ptr(), sd[p + "1.running_var"].data_ptr()
+            eh = ctypes.c_void_p()
+            _lib.check(lib.ttsx_encoder_convs_create(ctypes.byref(ew), _lib.current_stream(), ctypes.byref(eh)),
+                       "ttsx_encoder_convs_create")
+            self._enc_handle = eh
         # encoder BiLSTM as a stock module
         lstm = torch.nn.LSTM(512, 256, num_layers=1, batch_first=True, bidirectional=True)
         with torch.no_grad():
@@ -192,17 +206,29 @@ class Tacotron2:
 
     # ---- forward pieces ----------------------------------------------------
     @torch.no_grad()
-    def encode(self, text):
-        """Embedding + Encoder.inference (Tacotron2/TTS/models.py:803-804, 449-454)."""
+    def encode(self, text, text_lengths=None):
+        """Embedding + Encoder.inference (Tacotron2/TTS/models.py:803-804, 449-454).  The three
+        conv blocks run in the HIP conv-stack kernel (position-major, so the embedding output is
+        consumed as it is); the embedding lookup and the BiLSTM are stock ops.  With
+        `text_lengths` every utterance is encoded as its unpadded batch-1 run would be."""
+        lib = _lib.load()
         sd = self._sd
-        x = F.embedding(text, sd["embedding.weight"]).transpose(1, 2)
-        for i in range(3):
-            p = "encoder.convolutions.%d.net." % i
-            x = F.conv1d(x, sd[p + "0.weight"], sd[p + "0.bias"], padding=2)
-            x = F.batch_norm(x, sd[p + "1.running_mean"], sd[p + "1.running_var"], sd[p + "1.weight"],
-                             sd[p + "1.bias"], training=False, eps=1e-5)
-            x = torch.relu(x)
-        out, _ = self._lstm(x.transpose(1, 2).contiguous())
+        x = F.embedding(text, sd["embedding.weight"]).contiguous()          # [B,T,512]
+        B, T, _ = x.shape
+        y = torch.empty_like(x)
+        lens = None
+        if text_lengths is not None:
+            lens = torch.as_tensor(text_lengths).to(device=x.device, dtype=torch.int32).contiguous()
+        with torch.cuda.device(x.device):
+            _lib.check(lib.ttsx_encoder_convs_run(self._enc_handle, _lib.ptr(x), _lib.ptr(lens), B, T, _lib.ptr(y),
+                                                  _lib.current_stream()), "ttsx_encoder_convs_run")
+        if lens is None:
+            out, _ = self._lstm(y)
+            return out.contiguous()
+        packed = torch.nn.utils.rnn.pack_padded_sequence(y, lens.cpu().long(), batch_first=True,
+                                                         enforce_sorted=False)
+        out, _ = self._lstm(packed)
+        out, _ = torch.nn.utils.rnn.pad_packed_sequence(out, batch_first=True, total_length=T)
         return out.contiguous()
 
     @torch.no_grad()
@@ -264,7 +290,7 @@ class Tacotron2:
         text = torch.as_tensor(text).to(self.device).long()
         if text.dim() != 2:
             raise ValueError("text must be [B, T]")
-        enc = self.encode(text)
+        enc = self.encode(text, text_lengths)
         mel, align, stop, n_steps, steps = self.decode(enc, text_lengths, fixed_steps)
         if not fixed_steps and steps == self.decoder.max_decoder_steps and \
                 bool((stop[:, -1] <= self.decoder.stop_threshold).any()):
