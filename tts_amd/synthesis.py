@@ -1,0 +1,91 @@
+"""Synthesis helpers with the reference's signatures (Tacotron2/TTS/utils.py:1422-1528).
+
+`text` may be a string only if a text front-end is supplied (`text_to_ids=`): the reference's
+front-end needs phonemizer + espeak, which is outside this path; an integer id sequence (list,
+ndarray or LongTensor) is accepted in place of the string and is what the tests use.
+"""
+import numpy as np
+import torch
+
+
+def text_to_seqvec(text, CONFIG, use_cuda, text_to_ids=None):
+    if isinstance(text, str):
+        if text_to_ids is None:
+            raise NotImplementedError("no text front-end: pass phoneme/character ids, or text_to_ids=")
+        seq = np.asarray(text_to_ids(text), dtype=np.int32)
+    else:
+        seq = np.asarray(text, dtype=np.int32).reshape(-1)
+    chars_var = torch.from_numpy(seq).unsqueeze(0)
+    if use_cuda:
+        chars_var = chars_var.cuda()
+    return chars_var.long()
+
+
+def run_model(model, inputs, CONFIG, truncated, speaker_id=None, style_mel=None):
+    if CONFIG.get("use_gst"):
+        raise NotImplementedError("GST is outside the accelerated path")
+    if truncated:
+        raise NotImplementedError("inference_truncated is outside the accelerated path")
+    return model.inference(inputs, speaker_ids=speaker_id)
+
+
+def parse_outputs(postnet_output, decoder_output, alignments):
+    postnet_output = postnet_output[0].data.cpu().numpy()
+    decoder_output = decoder_output[0].data.cpu().numpy()
+    alignment = alignments[0].cpu().data.numpy()
+    return postnet_output, decoder_output, alignment
+
+
+def trim_silence(wav, ap):
+    return wav[:ap.find_endpoint(wav)]
+
+
+def inv_spectrogram(postnet_output, ap, CONFIG, init_phase=None):
+    if CONFIG.model in ["Tacotron", "TacotronGST"]:
+        return ap.inv_spectrogram(postnet_output.T, init_phase=init_phase)
+    return ap.inv_mel_spectrogram(postnet_output.T, init_phase=init_phase)
+
+
+def id_to_torch(speaker_id):
+    if speaker_id is not None:
+        speaker_id = torch.from_numpy(np.asarray(speaker_id)).unsqueeze(0)
+    return speaker_id
+
+
+def synthesis(model, text, CONFIG, use_cuda, ap, speaker_id=None, style_wav=None, truncated=False,
+              enable_eos_bos_chars=False, do_trim_silence=False, text_to_ids=None, init_phase=None):
+    """Same contract as the reference `synthesis` (utils.py:1482-1528): returns
+    (wav, alignment, decoder_output, postnet_output, stop_tokens)."""
+    if CONFIG.model == "TacotronGST" and style_wav is not None:
+        raise NotImplementedError("GST is outside the accelerated path")
+    inputs = text_to_seqvec(text, CONFIG, use_cuda, text_to_ids)
+    speaker_id = id_to_torch(speaker_id)
+    decoder_output, postnet_output, alignments, stop_tokens = run_model(
+        model, inputs, CONFIG, truncated, speaker_id, None)
+    postnet_output, decoder_output, alignment = parse_outputs(postnet_output, decoder_output, alignments)
+    wav = inv_spectrogram(postnet_output, ap, CONFIG, init_phase)
+    if do_trim_silence:
+        wav = trim_silence(wav, ap)
+    return wav, alignment, decoder_output, postnet_output, stop_tokens
+
+
+class Synthesizer(object):
+    """Per-sentence loop of the reference server (Tacotron2/TTS/synthesizer.py:141-174) on
+    id sequences: inference -> inv_mel_spectrogram -> endpoint trim -> concat with 10 000 zeros."""
+
+    def __init__(self, model, ap, config):
+        self.model, self.ap, self.tts_config = model, ap, config
+
+    def tts_ids(self, sentences_ids, init_phases=None):
+        from .audio import wav_bytes
+        wavs = []
+        for i, ids in enumerate(sentences_ids):
+            inputs = text_to_seqvec(ids, self.tts_config, True)
+            decoder_output, postnet_output, alignments, _ = run_model(self.model, inputs, self.tts_config, False)
+            postnet_output, _, _ = parse_outputs(postnet_output, decoder_output, alignments)
+            ph = None if init_phases is None else init_phases[i]
+            wav = inv_spectrogram(postnet_output, self.ap, self.tts_config, ph)
+            wav = trim_silence(wav, self.ap)
+            wavs += list(wav)
+            wavs += [0] * 10000
+        return wav_bytes(self.ap, np.asarray(wavs))
