@@ -133,8 +133,11 @@ def gen_t2audio():
 
 # ------------------------------------------------------------------ Tacotron (v1)
 T1_CASES = [
-    ("t1_T40", 40, 21),
-    ("t1_T100", 100, 22),
+    # name, T_in, ids seed, max_decoder_steps
+    ("t1_T40_stop", 40, 21, 500),      # stop token > 0.6 once t > T/4
+    ("t1_T100_max40", 100, 22, 40),    # runs into the max_decoder_steps guard (41 steps)
+    ("t1_T28_stop", 28, 23, 500),
+    ("t1_T1_attn_end", 1, 24, 500),    # attention on the last position > 0.6 ends it after one step
 ]
 
 
@@ -143,15 +146,16 @@ def gen_t1():
     sys.path.insert(0, os.path.join(REF, "Tacotron"))
     from TTS.models import Tacotron  # the reference implementation
     from TTS.utils import AudioProcessor
-    for name, T, ids_seed in T1_CASES:
+    for name, T, ids_seed, max_steps in T1_CASES:
         sd = synthetic.t1_state_dict(seed=0)
         model = Tacotron(num_chars=61, r=2, memory_size=5)
         model.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
         model.eval()
+        model.decoder.max_decoder_steps = max_steps
         ids = synthetic.t1_text_ids(ids_seed, T)
         with torch.no_grad():
             mel, lin, align, stop = model.forward(torch.as_tensor(ids))
-        meta = dict(weight_seed=0, ids_seed=ids_seed, T_in=T, r=2, memory_size=5)
+        meta = dict(weight_seed=0, ids_seed=ids_seed, T_in=T, r=2, memory_size=5, max_decoder_steps=max_steps)
         np.savez_compressed(os.path.join(GOLD, name + ".npz"), meta=json.dumps(meta), ids=ids,
                             mel=mel.numpy(), linear=lin.numpy(), alignments=align.numpy(),
                             stop_tokens=stop.numpy())

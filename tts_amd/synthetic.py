@@ -189,39 +189,39 @@ def _gru(sd, seed, prefix, in_dim, hid, gain=1.0, cell=True, suffix=""):
         sd[key] = uniform(seed, key, shape, -a, a)
 
 
-def _cbhg(sd, seed, prefix, in_dim, K, bank, projections, highway_dim, gru_dim, pre_highway):
+def _cbhg(sd, seed, prefix, in_dim, K, bank, projections, highway_dim, gru_dim, pre_highway, gain=1.0, hw=1.0):
     for k in range(1, K + 1):
         p = "%s.conv1d_banks.%d" % (prefix, k - 1)
-        a = 1.0 / np.sqrt(in_dim * k)
+        a = gain / np.sqrt(in_dim * k)
         sd[p + ".conv1d.weight"] = uniform(seed, p + ".conv1d.weight", (bank, in_dim, k), -a, a)
         _bn(sd, seed, p + ".bn", bank)
     cin = bank * K
     for i, cout in enumerate(projections):
         p = "%s.conv1d_projections.%d" % (prefix, i)
-        a = 1.0 / np.sqrt(cin * 3)
+        a = gain / np.sqrt(cin * 3)
         sd[p + ".conv1d.weight"] = uniform(seed, p + ".conv1d.weight", (cout, cin, 3), -a, a)
         _bn(sd, seed, p + ".bn", cout)
         cin = cout
     if pre_highway:
-        _lin(sd, seed, prefix + ".pre_highway", highway_dim, projections[-1], bias=False)
+        _lin(sd, seed, prefix + ".pre_highway", highway_dim, projections[-1], hw, bias=False)
     for i in range(4):
-        _lin(sd, seed, "%s.highways.%d.H" % (prefix, i), highway_dim, highway_dim)
-        _lin(sd, seed, "%s.highways.%d.T" % (prefix, i), highway_dim, highway_dim)
+        _lin(sd, seed, "%s.highways.%d.H" % (prefix, i), highway_dim, highway_dim, hw)
+        _lin(sd, seed, "%s.highways.%d.T" % (prefix, i), highway_dim, highway_dim, hw)
     for sfx in ("_l0", "_l0_reverse"):
-        _gru(sd, seed, prefix + ".gru", highway_dim, gru_dim, suffix=sfx)
+        _gru(sd, seed, prefix + ".gru", highway_dim, gru_dim, hw, suffix=sfx)
 
 
 def t1_state_dict(seed=0, num_chars=61, r=2, memory_size=5, gains=None):
     """Synthetic Tacotron (v1) `state_dict`; shapes follow
     Tacotron/TTS/models.py:336-410 (CBHG), 487-536 (Decoder), 669-690."""
-    g = dict(rnn=2.0, proj=3.0, v=20.0, loc=6.0, stop=8.0)
+    g = dict(rnn=3.0, proj=8.0, v=20.0, loc=6.0, stop=30.0, stop_bias=None, cbhg=2.0, last=8.0, hw=2.0)
     if gains:
         g.update(gains)
     sd = OrderedDict()
     sd["embedding.weight"] = normal(seed, "embedding.weight", (num_chars, 256), 0.0, 0.3)
     _lin(sd, seed, "encoder.prenet.layers.0", 256, 256)
     _lin(sd, seed, "encoder.prenet.layers.1", 128, 256)
-    _cbhg(sd, seed, "encoder.cbhg.cbhg", 128, 16, 128, [128, 128], 128, 128, False)
+    _cbhg(sd, seed, "encoder.cbhg.cbhg", 128, 16, 128, [128, 128], 128, 128, False, g["cbhg"], g["hw"])
     mem_in = 80 * memory_size if memory_size > 0 else 80 * r
     _lin(sd, seed, "decoder.prenet.layers.0", 256, mem_in)
     _lin(sd, seed, "decoder.prenet.layers.1", 128, 256)
@@ -241,8 +241,10 @@ def t1_state_dict(seed=0, num_chars=61, r=2, memory_size=5, gains=None):
     sd["decoder.memory_init.weight"] = normal(seed, "dec.mem_init", (1, mem_in), 0.0, 0.3)
     sd["decoder.decoder_rnn_inits.weight"] = normal(seed, "dec.rnn_inits", (2, 256), 0.0, 0.3)
     _lin(sd, seed, "decoder.stopnet.linear", 1, 256 + 80 * r, g["stop"])
-    _cbhg(sd, seed, "postnet.cbhg", 80, 8, 128, [256, 80], 128, 128, True)
-    _lin(sd, seed, "last_linear.0", 1025, 256, 2.0)
+    if g["stop_bias"] is not None:
+        sd["decoder.stopnet.linear.bias"] = np.full((1,), g["stop_bias"], dtype=np.float32)
+    _cbhg(sd, seed, "postnet.cbhg", 80, 8, 128, [256, 80], 128, 128, True, g["cbhg"], g["hw"])
+    _lin(sd, seed, "last_linear.0", 1025, 256, g["last"])
     return sd
 
 
