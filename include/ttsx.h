@@ -174,6 +174,100 @@ int ttsx_encoder_convs_destroy(ttsx_encoder_convs* p);
 int ttsx_encoder_convs_run(ttsx_encoder_convs* p, const float* x, const int32_t* lengths, int B, int T, float* out,
                            void* stream);
 
+/* ------------------------------------------------------------------ Tacotron (v1)
+ * Replaces Tacotron.forward in eval mode, Tacotron/TTS/models.py:692-700:
+ *   encoder   Prenet (:250-253) + CBHG K=16 (:412-434, BatchNormConv1d :307-313, Highway :331-334)
+ *   decoder   greedy Decoder.forward (:586-645) with AttentionRNNCell (:124-156),
+ *             LocationSensitiveAttention (:71-88), StopNet (:663-667), learned initial states (:538-556)
+ *   postnet   PostCBHG K=8 (:471-484) + last_linear + sigmoid (:690, :699)
+ * Tensor names are the reference state_dict keys.  The embedding lookup stays a stock op.
+ */
+typedef struct {
+  int K;                          /* number of conv banks: 16 (encoder) or 8 (postnet) */
+  int in_features;                /* 128 (encoder) or 80 (postnet) */
+  int proj_dims[2];               /* conv_projections: {128,128} or {256,80} */
+  const float* bank_w[16];        /* conv1d_banks.k.conv1d.weight [128,in,k+1] */
+  const float* bank_bn_weight[16];/* conv1d_banks.k.bn.{weight,bias,running_mean,running_var} [128] */
+  const float* bank_bn_bias[16];
+  const float* bank_bn_mean[16];
+  const float* bank_bn_var[16];
+  const float* proj_w[2];         /* conv1d_projections.i.conv1d.weight [out,in,3] */
+  const float* proj_bn_weight[2];
+  const float* proj_bn_bias[2];
+  const float* proj_bn_mean[2];
+  const float* proj_bn_var[2];
+  const float* pre_highway_w;     /* pre_highway.weight [128,proj_dims[1]] or NULL (encoder) */
+  const float* hw_H_w[4];         /* highways.i.H.weight [128,128], .bias [128] */
+  const float* hw_H_b[4];
+  const float* hw_T_w[4];         /* highways.i.T.weight / .bias */
+  const float* hw_T_b[4];
+  const float* gru_w_ih[2];       /* gru.weight_ih_l0 [384,128], gru.weight_ih_l0_reverse */
+  const float* gru_w_hh[2];       /* gru.weight_hh_l0 [384,128], ..._reverse */
+  const float* gru_b_ih[2];
+  const float* gru_b_hh[2];
+} ttsx_cbhg_weights;
+
+typedef struct {
+  const float* enc_prenet_w[2];   /* encoder.prenet.layers.{0,1}.weight [256,256], [128,256]; .bias */
+  const float* enc_prenet_b[2];
+  ttsx_cbhg_weights enc_cbhg;     /* encoder.cbhg.cbhg.* */
+  const float* dec_prenet_w[2];   /* decoder.prenet.layers.{0,1}.weight [256,80*memory_size], [128,256]; .bias */
+  const float* dec_prenet_b[2];
+  const float* att_rnn_w_ih;      /* decoder.attention_rnn.rnn_cell.weight_ih [768,384] (input [prenet 128; context 256]) */
+  const float* att_rnn_w_hh;      /* [768,256] */
+  const float* att_rnn_b_ih;
+  const float* att_rnn_b_hh;
+  const float* loc_conv_w;        /* ...alignment_model.loc_conv.1.weight [32,2,31] */
+  const float* loc_linear_w;      /* ...loc_linear.weight [128,32], .bias [128] */
+  const float* loc_linear_b;
+  const float* query_w;           /* ...query_layer.weight [128,256], .bias */
+  const float* query_b;
+  const float* annot_w;           /* ...annot_layer.weight [128,256], .bias */
+  const float* annot_b;
+  const float* v_w;               /* ...v.weight [1,128] (no bias) */
+  const float* proj_dec_in_w;     /* decoder.project_to_decoder_in.weight [256,512], .bias */
+  const float* proj_dec_in_b;
+  const float* dec_rnn_w_ih[2];   /* decoder.decoder_rnns.{0,1}.weight_ih [768,256] ... */
+  const float* dec_rnn_w_hh[2];
+  const float* dec_rnn_b_ih[2];
+  const float* dec_rnn_b_hh[2];
+  const float* proj_mel_w;        /* decoder.proj_to_mel.weight [80*r,256], .bias */
+  const float* proj_mel_b;
+  const float* att_rnn_init;      /* decoder.attention_rnn_init.weight [1,256] */
+  const float* memory_init;       /* decoder.memory_init.weight [1,80*memory_size] */
+  const float* dec_rnn_inits;     /* decoder.decoder_rnn_inits.weight [2,256] */
+  const float* stop_w;            /* decoder.stopnet.linear.weight [1,256+80*r], .bias [1] */
+  const float* stop_b;
+  ttsx_cbhg_weights post_cbhg;    /* postnet.cbhg.* */
+  const float* last_linear_w;     /* last_linear.0.weight [1025,256], .bias */
+  const float* last_linear_b;
+} ttsx_t1_weights;
+
+typedef struct ttsx_t1 ttsx_t1;
+
+int ttsx_t1_create(const ttsx_t1_weights* w, int r, int memory_size, int linear_dim, void* stream, ttsx_t1** out);
+int ttsx_t1_destroy(ttsx_t1* m);
+/* emb [B,T,256] embedded characters -> enc [B,T,256] (Encoder.forward, :459-469).
+ * lengths [B] int32 valid positions per utterance or NULL (= T): positions >= length are treated
+ * as absent, so every utterance is encoded as its unpadded batch-1 run would be; their rows of
+ * enc are zero. */
+int ttsx_t1_encoder_run(ttsx_t1* m, const float* emb, const int32_t* lengths, int B, int T, float* enc, void* stream);
+/* Greedy decode (Decoder.forward with memory=None in eval mode).  Stops after step t (1-based)
+ * when t > T/4 and (stop > 0.6 or attention on the last position > 0.6), or when
+ * t > max_decoder_steps (:635-640), so at most max_decoder_steps+1 steps run.
+ *   mel   [B, (max_decoder_steps+1)*r, 80]  sigmoid-bounded frames
+ *   align [B, max_decoder_steps+1, T]       stop [B, max_decoder_steps+1]
+ *   n_steps [B] int32 steps each utterance ran; *steps_run_host = their maximum.
+ * lengths [B] int32 or NULL as above: attention runs over the first lengths[b] positions and the
+ * stop rule uses that length; align columns beyond it are zero.  Rows of mel / align / stop past
+ * n_steps[b] are not written.  T <= 512.  Synchronises `stream`. */
+int ttsx_t1_decoder_run(ttsx_t1* m, const float* enc, const int32_t* lengths, int B, int T, int max_decoder_steps,
+                        float* mel, float* align, float* stop, int32_t* n_steps, int* steps_run_host, void* stream);
+/* mel [B,F,80] -> linear [B,F,linear_dim] = sigmoid(last_linear(PostCBHG(mel))) (:698-699).
+ * n_frames [B] int32 valid frames per utterance or NULL (= F); rows past it are unspecified. */
+int ttsx_t1_postnet_run(ttsx_t1* m, const float* mel, const int32_t* n_frames, int B, int F, float* linear,
+                        void* stream);
+
 /* ------------------------------------------------------------------ vocoder (Griffin-Lim)
  * Replaces the inverse path of AudioProcessor: Tacotron2/TTS/utils.py:834-851
  * (_denormalize), 866-868 (_db_to_amp), 802-804 (_mel_to_linear), 922-929

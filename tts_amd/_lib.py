@@ -39,6 +39,34 @@ class EncoderConvWeights(Structure):
                 ("bn_mean", _fp * 3), ("bn_var", _fp * 3)]
 
 
+class CbhgWeights(Structure):
+    _fields_ = [("K", c_int), ("in_features", c_int), ("proj_dims", c_int * 2),
+                ("bank_w", _fp * 16), ("bank_bn_weight", _fp * 16), ("bank_bn_bias", _fp * 16),
+                ("bank_bn_mean", _fp * 16), ("bank_bn_var", _fp * 16),
+                ("proj_w", _fp * 2), ("proj_bn_weight", _fp * 2), ("proj_bn_bias", _fp * 2),
+                ("proj_bn_mean", _fp * 2), ("proj_bn_var", _fp * 2),
+                ("pre_highway_w", _fp),
+                ("hw_H_w", _fp * 4), ("hw_H_b", _fp * 4), ("hw_T_w", _fp * 4), ("hw_T_b", _fp * 4),
+                ("gru_w_ih", _fp * 2), ("gru_w_hh", _fp * 2), ("gru_b_ih", _fp * 2), ("gru_b_hh", _fp * 2)]
+
+
+class T1Weights(Structure):
+    _fields_ = [("enc_prenet_w", _fp * 2), ("enc_prenet_b", _fp * 2),
+                ("enc_cbhg", CbhgWeights),
+                ("dec_prenet_w", _fp * 2), ("dec_prenet_b", _fp * 2),
+                ("att_rnn_w_ih", _fp), ("att_rnn_w_hh", _fp), ("att_rnn_b_ih", _fp), ("att_rnn_b_hh", _fp),
+                ("loc_conv_w", _fp), ("loc_linear_w", _fp), ("loc_linear_b", _fp),
+                ("query_w", _fp), ("query_b", _fp), ("annot_w", _fp), ("annot_b", _fp), ("v_w", _fp),
+                ("proj_dec_in_w", _fp), ("proj_dec_in_b", _fp),
+                ("dec_rnn_w_ih", _fp * 2), ("dec_rnn_w_hh", _fp * 2), ("dec_rnn_b_ih", _fp * 2),
+                ("dec_rnn_b_hh", _fp * 2),
+                ("proj_mel_w", _fp), ("proj_mel_b", _fp),
+                ("att_rnn_init", _fp), ("memory_init", _fp), ("dec_rnn_inits", _fp),
+                ("stop_w", _fp), ("stop_b", _fp),
+                ("post_cbhg", CbhgWeights),
+                ("last_linear_w", _fp), ("last_linear_b", _fp)]
+
+
 class StftParams(Structure):
     _fields_ = [("n_fft", c_int), ("hop_length", c_int), ("win_length", c_int), ("pad_mode", c_int)]
 
@@ -67,6 +95,12 @@ PROTOTYPES = {
     "ttsx_encoder_convs_create": (c_int, [POINTER(EncoderConvWeights), c_void_p, POINTER(c_void_p)]),
     "ttsx_encoder_convs_destroy": (c_int, [c_void_p]),
     "ttsx_encoder_convs_run": (c_int, [c_void_p, _fp, _fp, c_int, c_int, _fp, c_void_p]),
+    "ttsx_t1_create": (c_int, [POINTER(T1Weights), c_int, c_int, c_int, c_void_p, POINTER(c_void_p)]),
+    "ttsx_t1_destroy": (c_int, [c_void_p]),
+    "ttsx_t1_encoder_run": (c_int, [c_void_p, _fp, _fp, c_int, c_int, _fp, c_void_p]),
+    "ttsx_t1_decoder_run": (c_int, [c_void_p, _fp, _fp, c_int, c_int, c_int, _fp, _fp, _fp, _fp, POINTER(c_int),
+                                    c_void_p]),
+    "ttsx_t1_postnet_run": (c_int, [c_void_p, _fp, _fp, c_int, c_int, _fp, c_void_p]),
     "ttsx_spec_to_mag": (c_int, [_fp, _fp, c_int, c_int, c_int, c_int, POINTER(AudioParams), _fp, c_void_p]),
     "ttsx_griffin_lim": (c_int, [_fp, _fp, _fp, c_int, c_int, POINTER(StftParams), c_int, c_float, _fp,
                                  c_void_p]),
