@@ -154,24 +154,9 @@ def main():
     phase = torch.rand(B, F_total, 1025, device=dev, generator=torch.Generator(device=dev).manual_seed(rank))
     wl = Workload(model, ap, ids, S, phase)
 
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    for _ in range(a.warmup):
-        wl.run()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        wl.run()
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    from tts_amd import corpus
+    # warm-up, then exactly `steps` timed passes between synchronise + barrier fences; max over ranks
+    dt = corpus.timed_steps(wl.run, a.steps, a.warmup, dist, dev)
     ms_per_step = dt / a.steps * 1e3
     frames_per_step = B * F_total * world
     value = frames_per_step / (ms_per_step * 1e-3)

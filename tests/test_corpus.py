@@ -1,0 +1,91 @@
+"""Host logic of the multi-GPU path: the corpus plan every rank derives on its own, and the
+two-scalar reporting exchange, run as two gloo ranks on the CPU."""
+import os
+import socket
+import time
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from tts_amd import corpus
+
+
+def test_plan_covers_every_utterance_once_for_any_world():
+    lengths = corpus.corpus_lengths(1000, seed=1234)
+    assert lengths.min() >= 20 and lengths.max() <= 200
+    batches = corpus.plan_batches(lengths, 64)
+    assert sorted(np.concatenate(batches).tolist()) == list(range(1000))
+    assert all(len(b) == 64 for b in batches[:-1]) and len(batches[-1]) == 1000 - 64 * 15
+    flat = lengths[np.concatenate(batches)]
+    assert (np.diff(flat) <= 0).all()                      # longest first
+    for world in (1, 2, 3, 8):
+        for policy in ("round_robin", "lpt"):
+            got = [corpus.rank_batches(lengths, 64, world, r, policy) for r in range(world)]
+            seen = sorted(int(i) for rb in got for b in rb for i in b)
+            assert seen == list(range(1000)), (world, policy)
+
+
+def test_lpt_balances_better_than_round_robin_on_sorted_batches():
+    lengths = corpus.corpus_lengths(4096, seed=1234)
+    batches = corpus.plan_batches(lengths, 64)
+    cost = np.array([len(b) * lengths[b].max() for b in batches])
+
+    def spread(policy):
+        loads = [cost[ix].sum() for ix in corpus.deal(batches, lengths, 8, policy)]
+        return max(loads) / (sum(loads) / 8)
+    assert spread("lpt") <= spread("round_robin")
+    assert spread("lpt") < 1.02
+
+
+def test_pad_batch_and_bad_arguments():
+    texts = [[5, 6, 7], [8], [9, 10]]
+    ids, lens = corpus.pad_batch(texts, [2, 0])
+    assert ids.tolist() == [[9, 10, 0], [5, 6, 7]] and lens.tolist() == [2, 3]
+    with pytest.raises(ValueError):
+        corpus.deal([np.array([0])], np.array([3]), 0)
+    with pytest.raises(ValueError):
+        corpus.deal([np.array([0])], np.array([3]), 2, "random")
+
+
+def test_single_process_timing_needs_no_process_group():
+    calls = []
+    dt = corpus.timed_steps(lambda: calls.append(1), steps=4, warmup=2)
+    assert len(calls) == 6 and dt >= 0.0
+    assert corpus.reduce_scalar(3.5, "sum") == 3.5
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _rank_main(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lengths = corpus.corpus_lengths(300, seed=7)
+        mine = corpus.rank_batches(lengths, 32, world, rank)
+        frames = float(sum(int(lengths[b].sum()) for b in mine))
+        # rank 1 is the slow one: the reported time must be its time on both ranks
+        dt = corpus.timed_steps(lambda: time.sleep(0.02 * (rank + 1)), steps=3, warmup=1, dist=dist)
+        total = corpus.reduce_scalar(frames, "sum", dist)
+        np.save(os.path.join(out_dir, "r%d.npy" % rank),
+                np.array([dt, total, frames] + sorted(int(i) for b in mine for i in b), dtype=np.float64))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_gloo_ranks_share_a_plan_and_agree_on_max_time_and_total(tmp_path):
+    port = _free_port()
+    mp.spawn(_rank_main, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (np.load(os.path.join(str(tmp_path), "r%d.npy" % r)) for r in range(2))
+    assert r0[0] == r1[0] and r0[0] >= 3 * 0.04                      # max over ranks, same on both
+    lengths = corpus.corpus_lengths(300, seed=7)
+    assert r0[1] == r1[1] == float(lengths.sum())                     # sum over ranks
+    assert r0[2] + r1[2] == r0[1]
+    ids0, ids1 = set(r0[3:].astype(int)), set(r1[3:].astype(int))
+    assert not (ids0 & ids1) and ids0 | ids1 == set(range(300))      # disjoint, complete

@@ -264,28 +264,37 @@ struct DecP {
   int T, max_steps, mem_dim, odim;
 };
 
-// out[r] = act(W[r][:] . x + bias[r]) for r < n_rows (n_rows % 4 == 0, n_cols % 4 == 0); x and out in LDS.
-// A wave takes four rows at a time so that four weight streams are in flight per lane.
-template <int ACT>
+// out[r] = act(W[r][:] . x + bias[r]) for r < n_rows (n_rows % RP == 0, n_cols % 4 == 0); x and out in LDS.
+// The weights come from L2 / Infinity Cache with microseconds of latency and a single workgroup
+// has to cover it alone, so a wave takes RP rows at a time: RP independent 16-byte loads per lane
+// in flight (RP = 16: 16 KiB per wave, 256 KiB per workgroup).
+template <int ACT, int RP>
 __device__ __forceinline__ void gemv_lds(const float* __restrict__ W, const float* __restrict__ bias,
                                          const float* x, int n_rows, int n_cols, float* out, int wave, int lane) {
   const float4* x4 = reinterpret_cast<const float4*>(x);
   const int nc4 = n_cols >> 2;
-  for (int r0 = wave * 4; r0 < n_rows; r0 += DEC_WAVES * 4) {
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int r0 = wave * RP; r0 < n_rows; r0 += DEC_WAVES * RP) {
+    float acc[RP];
+#pragma unroll
+    for (int i = 0; i < RP; ++i) acc[i] = 0.f;
     const float4* w0 = reinterpret_cast<const float4*>(W + (size_t)r0 * n_cols);
     for (int c = lane; c < nc4; c += 64) {
+      float4 wv[RP];
+#pragma unroll
+      for (int i = 0; i < RP; ++i) wv[i] = w0[(size_t)i * nc4 + c];
       const float4 xv = x4[c];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float4 wv = w0[(size_t)i * nc4 + c];
-        acc[i] += wv.x * xv.x + wv.y * xv.y + wv.z * xv.z + wv.w * xv.w;
-      }
+      for (int i = 0; i < RP; ++i) acc[i] += wv[i].x * xv.x + wv[i].y * xv.y + wv[i].z * xv.z + wv[i].w * xv.w;
     }
+    // butterfly: after the exchange every lane holds the full sum of each row
 #pragma unroll
-    for (int i = 0; i < 4; ++i) acc[i] = wave_sum(acc[i]);
-    if (lane < 4) {
-      float v = (lane == 0 ? acc[0] : lane == 1 ? acc[1] : lane == 2 ? acc[2] : acc[3]) + (bias ? bias[r0 + lane] : 0.f);
+    for (int i = 0; i < RP; ++i) acc[i] = wave_sum(acc[i]);
+    float mine = 0.f;
+#pragma unroll
+    for (int i = 0; i < RP; ++i)
+      if (lane == i) mine = acc[i];
+    if (lane < RP) {
+      float v = mine + (bias ? bias[r0 + lane] : 0.f);
       if (ACT == 1) v = fmaxf(v, 0.f);
       else if (ACT == 2) v = sigmoidf_(v);
       out[r0 + lane] = v;
@@ -302,7 +311,8 @@ __device__ __forceinline__ float gru_point(const float* gi, const float* gh, flo
 }
 
 __global__ __launch_bounds__(DEC_THREADS) void t1_decoder_kernel(DecP p) {
-  const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: weight row addresses stay in SGPRs
   const int Tp = p.T;                                                       // row pitch of enc / annot / align
   const int T = p.enc_len ? min(max(p.enc_len[b], 1), Tp) : Tp;             // positions attended
   extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -351,19 +361,23 @@ __global__ __launch_bounds__(DEC_THREADS) void t1_decoder_kernel(DecP p) {
 
   int t = 0;
   for (;;) {
+    // an opaque copy of the lane id per step: keeps the weight-address arithmetic of the nine
+    // GEMVs inside the step instead of hoisted above the loop, where it would not fit in registers
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
     // ---- prenet (dropout is identity in eval)
-    gemv_lds<1>(p.pre_w0, p.pre_b0, s_mem, PRE0, p.mem_dim, s_p1, wave, lane);
+    gemv_lds<1, 16>(p.pre_w0, p.pre_b0, s_mem, PRE0, p.mem_dim, s_p1, wave, ln);
     __syncthreads();
-    gemv_lds<1>(p.pre_w1, p.pre_b1, s_p1, PRE1, PRE0, s_pc, wave, lane);
+    gemv_lds<1, 8>(p.pre_w1, p.pre_b1, s_p1, PRE1, PRE0, s_pc, wave, ln);
     __syncthreads();
     // ---- attention GRU on [prenet ; context]
-    gemv_lds<0>(p.att_w_ih, p.att_b_ih, s_pc, 3 * RNN_D, PRE1 + ENC_D, s_gi, wave, lane);
-    gemv_lds<0>(p.att_w_hh, p.att_b_hh, s_hc, 3 * RNN_D, RNN_D, s_gh, wave, lane);
+    gemv_lds<0, 16>(p.att_w_ih, p.att_b_ih, s_pc, 3 * RNN_D, PRE1 + ENC_D, s_gi, wave, ln);
+    gemv_lds<0, 16>(p.att_w_hh, p.att_b_hh, s_hc, 3 * RNN_D, RNN_D, s_gh, wave, ln);
     __syncthreads();
     if (tid < RNN_D) s_hc[tid] = gru_point(s_gi, s_gh, s_hc[tid], tid);
     __syncthreads();
     // ---- query, location features
-    gemv_lds<0>(p.query_w, p.query_b, s_hc, ATT_D, RNN_D, s_q, wave, lane);
+    gemv_lds<0, 8>(p.query_w, p.query_b, s_hc, ATT_D, RNN_D, s_q, wave, ln);
     {
       const int f = tid & 31;
       for (int tt = tid >> 5; tt < T; tt += DEC_THREADS / 32) {
@@ -429,13 +443,13 @@ __global__ __launch_bounds__(DEC_THREADS) void t1_decoder_kernel(DecP p) {
     }
     __syncthreads();
     // ---- decoder input and the two residual GRUs
-    gemv_lds<0>(p.pd_w, p.pd_b, s_hc, RNN_D, RNN_D + ENC_D, s_d, wave, lane);
+    gemv_lds<0, 16>(p.pd_w, p.pd_b, s_hc, RNN_D, RNN_D + ENC_D, s_d, wave, ln);
     __syncthreads();
 #pragma unroll
     for (int l = 0; l < 2; ++l) {
       float* s_h = l == 0 ? s_h1 : s_h2;
-      gemv_lds<0>(p.rnn_w_ih[l], p.rnn_b_ih[l], s_d, 3 * RNN_D, RNN_D, s_gi, wave, lane);
-      gemv_lds<0>(p.rnn_w_hh[l], p.rnn_b_hh[l], s_h, 3 * RNN_D, RNN_D, s_gh, wave, lane);
+      gemv_lds<0, 16>(p.rnn_w_ih[l], p.rnn_b_ih[l], s_d, 3 * RNN_D, RNN_D, s_gi, wave, ln);
+      gemv_lds<0, 16>(p.rnn_w_hh[l], p.rnn_b_hh[l], s_h, 3 * RNN_D, RNN_D, s_gh, wave, ln);
       __syncthreads();
       if (tid < RNN_D) {
         const float hn = gru_point(s_gi, s_gh, s_h[tid], tid);
@@ -445,7 +459,7 @@ __global__ __launch_bounds__(DEC_THREADS) void t1_decoder_kernel(DecP p) {
       __syncthreads();
     }
     // ---- mel frames (sigmoid) and stop token
-    gemv_lds<2>(p.mel_w, p.mel_b, s_d, p.odim, RNN_D, s_d + RNN_D, wave, lane);
+    gemv_lds<2, 16>(p.mel_w, p.mel_b, s_d, p.odim, RNN_D, s_d + RNN_D, wave, ln);
     __syncthreads();
     {
       float part = 0.f;
