@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Run only the Tacotron2 decoder loop (for kernel profiles): dec_only.py B T steps."""
+"""Run only the Tacotron2 decoder loop (for kernel profiles and step timing): dec_only.py B T steps.
+Prints the marginal time per step (difference between a run of `steps` and one of `steps`/2 steps,
+so that per-run set-up cancels) and the all-in figure."""
 import os
 import sys
 import time
@@ -14,9 +16,21 @@ B, T, S = (int(x) for x in sys.argv[1:4])
 model, ap, sd = bench.build_model(0, 1)
 ids = torch.as_tensor(synthetic.t2_text_ids(5, B, T)).cuda()
 enc = model.encode(ids)
-model.decode(enc, None, fixed_steps=S)
-torch.cuda.synchronize()
-t0 = time.perf_counter()
-model.decode(enc, None, fixed_steps=S)
-torch.cuda.synchronize()
-print("B=%d T=%d: %.2f us/step" % (B, T, (time.perf_counter() - t0) / S * 1e6))
+
+
+def run(steps, reps=3):
+    model.decode(enc, None, fixed_steps=steps)
+    torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        model.decode(enc, None, fixed_steps=steps)
+        torch.cuda.synchronize()
+        best = min(best, time.perf_counter() - t0)
+    return best
+
+
+full, half = run(S), run(S // 2)
+print("B=%d T=%d split=%s: marginal %.2f us/step, all-in %.2f us/step (%d steps), fixed %.2f ms" %
+      (B, T, os.environ.get("TTSX_SPLIT", "auto"), (full - half) / (S - S // 2) * 1e6, full / S * 1e6, S,
+       (2 * half - full) * 1e3))

@@ -11,8 +11,17 @@
 //   h_d = LSTMCell([h_a; ctx], h_d, c_d)
 //   o   = W_o [h_d; ctx] + b_o ;  stop = sigmoid(w_s [h_d; o] + b_s)
 //
-// Launches per step (all stream-ordered, captured into a hipGraph per chunk of steps):
+// Launches per step (captured into a hipGraph per chunk of steps):
 //   prenet layer 2 | attention LSTM | query | energies | normalise+context | decoder LSTM | projection
+// Each LSTM is cut in two along K.  The columns whose inputs are known early (attention LSTM:
+// previous context and hidden state; decoder LSTM: new attention hidden state and own previous
+// hidden state) are multiplied by "partial" work that leaves raw gate sums in a buffer; the launch
+// on the serial path only adds the late columns (prenet output, 256; new context, 512) and applies
+// the cell update.  The partial work is bandwidth/MFMA-bound while the small launches on the serial
+// path (prenet, query, energies, context, projection) are latency-bound, so the partial row blocks
+// are dealt out in three pieces that ride along in the same launches as those small kernels
+// (a launch = workgroups of the small op first, then workgroups of a partial piece): the heavy
+// streaming runs in the shadow of the serial chain without any cross-stream synchronisation.
 // The projection launch carries, besides the 80*r_init mel rows, two sets of composed rows so
 // that nothing else sits on the serial path between two steps:
 //   * one row  u = [w_s,h + W_o,h^T w_s,o ; W_o,c^T w_s,o]  whose product with [h_d; ctx] is the
@@ -32,6 +41,8 @@
 // Two engines share the packed weights: B <= 2 utterances run a GEMV engine (weights straight
 // to VGPRs with every load of a wave in flight at once, activations staged in LDS; this regime
 // is HBM-bandwidth bound), larger batches run the fp32 MFMA engine.
+#include <stdlib.h>
+
 #include <algorithm>
 #include <vector>
 
@@ -51,8 +62,6 @@ struct RunCtx {
   float* align;      // [B, align_rows, T]
   float* stop;       // [B, stop_rows]
   int32_t* n_steps;  // [B]
-  const float* enc;  // [B, T, 512]
-  const int32_t* enc_len;
 };
 
 constexpr int ENC_DIM = 512, QUERY_DIM = 1024, DEC_DIM = 1024, PRENET_DIM = 256, ATT_DIM = 128;
@@ -96,6 +105,14 @@ __global__ void pack_bias_kernel(float* __restrict__ dst, const float* __restric
     if (b2) v += b2[row];
   }
   dst[i] = v;
+}
+
+// dst row = [src columns k1 .. k1+k2-1 | src columns 0 .. k1-1]; one block per row
+__global__ void swap_cols_kernel(float* __restrict__ dst, const float* __restrict__ src, int k1, int k2) {
+  const size_t row = blockIdx.x;
+  const int K = k1 + k2;
+  for (int k = threadIdx.x; k < K; k += blockDim.x)
+    dst[row * K + k] = src[row * K + (k < k2 ? k1 + k : k - k2)];
 }
 
 // Prenet layer with eval-mode BatchNorm folded in (row-major [n_out][n_in]):
@@ -154,18 +171,25 @@ __global__ void compose_proj_ext_kernel(float* __restrict__ ext_w, float* __rest
 // ------------------------------------------------------------------ GEMM / GEMV engines
 struct Seg {
   const float* x[2];  // quad-interleaved activation buffer(s)
-  int sel;            // 0: x[0]; 1: x[step&1] (state before this step); 2: x[(step+1)&1] (new state)
+  int sel;            // 0: x[0]; 1: x[parity] (state before this step); 2: x[parity^1] (new state)
   int kgroups;        // K of the segment / 16
 };
 
-enum { MODE_LINEAR = 0, MODE_LSTM = 1, MODE_PROJ = 2 };
+enum { MODE_LINEAR = 0, MODE_LSTM = 1, MODE_PROJ = 2, MODE_PARTIAL = 3 };
 
+// Everything a launch needs before its arithmetic is a kernel argument (no pointer is fetched
+// from device memory first), so that all global loads of a workgroup - weights, activations and
+// the operands of the epilogue - leave in one burst and the launch costs one memory round trip.
 struct GemmP {
   const float* Wp;
   const float* bias;
   Seg seg[3];
   int nseg, KG, Bpad;
-  float* out[2];  // LINEAR/PROJ: out[0] quad layout; LSTM: h ping-pong pair, written at (step+1)&1
+  int kg0, kg_stride;  // first k-group of this launch inside a row block, k-groups per row block
+  int rb0, nrb;        // row blocks rb0 .. rb0+nrb-1 are this launch's; workgroup id = tile * nrb + (rb - rb0)
+  int parity;          // (decoder steps completed before this one) & 1: selects the h ping-pong buffers
+  float* gates;        // PARTIAL: raw sums out (quad layout); LSTM: sums of the partial launch, added in
+  float* out[2];  // LINEAR/PROJ: out[0] quad layout; LSTM: h ping-pong pair, written at parity^1
   float* c;       // LSTM cell state, quad layout
   float* x1;      // PROJ: prenet layer-1 activations for the next step, quad layout
   int relu;       // LINEAR: apply ReLU
@@ -174,18 +198,41 @@ struct GemmP {
   int step_in_chunk;
 };
 
-// Finish one quad (4 consecutive output rows, bias already added) of utterance column b.
+// Operands of the epilogue of one (quad, utterance) pair, fetched while the weights stream.
+struct Pre {
+  float4 bias, gates;
+  float c;
+};
 template <int MODE>
-__device__ inline void epilogue_quad(const GemmP& p, int step, int quad, int b, f32x4 v) {
+__device__ __forceinline__ Pre prefetch_quad(const GemmP& p, int quad, int b) {
+  Pre r;
+  r.bias = make_float4(0.f, 0.f, 0.f, 0.f), r.gates = r.bias, r.c = 0.f;
+  if (MODE != MODE_PARTIAL) r.bias = reinterpret_cast<const float4*>(p.bias)[quad];
+  if (MODE == MODE_LSTM) {
+    r.c = p.c[qidx(quad, b, p.Bpad)];
+    if (p.gates) r.gates = reinterpret_cast<const float4*>(p.gates)[(size_t)quad * p.Bpad + b];
+  }
+  return r;
+}
+
+// Finish one quad (4 consecutive output rows) of utterance column b.
+template <int MODE>
+__device__ __forceinline__ void epilogue_quad(const GemmP& p, int quad, int b, f32x4 v, const Pre& pre) {
   const int Bpad = p.Bpad;
+  if (MODE == MODE_PARTIAL) {
+    reinterpret_cast<float4*>(p.gates)[(size_t)quad * Bpad + b] = make_float4(v[0], v[1], v[2], v[3]);
+    return;
+  }
+  v[0] += pre.bias.x, v[1] += pre.bias.y, v[2] += pre.bias.z, v[3] += pre.bias.w;
   if (MODE == MODE_LSTM) {
     // the four rows are gates i,f,g,o of hidden unit `quad`
     const size_t idx = qidx(quad, b, Bpad);
-    const float c_old = p.c[idx];
-    const float c_new = sigmoidf_(v[1]) * c_old + sigmoidf_(v[0]) * tanhf(v[2]);
+    v[0] += pre.gates.x, v[1] += pre.gates.y, v[2] += pre.gates.z, v[3] += pre.gates.w;
+    const float c_new = sigmoidf_(v[1]) * pre.c + sigmoidf_(v[0]) * tanhf(v[2]);
     const float h_new = sigmoidf_(v[3]) * tanhf(c_new);
     p.c[idx] = c_new;
-    p.out[(step + 1) & 1][idx] = h_new;
+    float* h_out = p.parity ? p.out[0] : p.out[1];
+    h_out[idx] = h_new;
   } else if (MODE == MODE_LINEAR) {
     if (p.relu) v = (f32x4){fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
     reinterpret_cast<float4*>(p.out[0])[(size_t)quad * Bpad + b] = make_float4(v[0], v[1], v[2], v[3]);
@@ -204,7 +251,7 @@ __device__ inline void epilogue_quad(const GemmP& p, int step, int quad, int b, 
         const float s = sigmoidf_(v[0]);
         cx->stop[(size_t)b * cx->stop_rows + cx->out_base + p.step_in_chunk] = s;
         if (s > cx->threshold && cx->n_steps[b] == 0) {
-          cx->n_steps[b] = step + 1;  // steps run so far, the stop frame included
+          cx->n_steps[b] = cx->base + p.step_in_chunk + 1;  // steps run so far, the stop frame included
           const int done = atomicAdd(&cx->n_done, 1) + 1;
           if (cx->free_running && done == cx->B) cx->all_done = 1;
         }
@@ -217,155 +264,182 @@ __device__ inline void epilogue_quad(const GemmP& p, int step, int quad, int b, 
   }
 }
 
-__device__ inline const float* seg_ptr(const Seg& sg, int step) {
-  return sg.sel == 0 ? sg.x[0] : sg.x[(step + (sg.sel == 2)) & 1];
+// (selects, not an index into x[]: a dynamically indexed copy of the argument struct would be
+// spilled to a per-lane array)
+__device__ __forceinline__ const float* seg_ptr(const Seg& sg, int parity) {
+  const float *a = sg.x[0], *b = sg.x[1];
+  const bool second = sg.sel != 0 && ((parity != 0) != (sg.sel == 2));
+  return second ? b : a;
 }
 
 // fp32 MFMA engine: one row block x NT column tiles of 16 utterances per workgroup, the K axis
 // split over the 8 waves (wave w takes k-groups w, w+8, ...), partial tiles combined through LDS.
 // KGW = k-groups per wave.  The k-loop is fully unrolled and software-pipelined: the loads of
 // k-group i+D are issued before the MFMAs of k-group i, so D groups (weights from HBM, activations
-// from L2) are always in flight per wave.
+// from L2) are always in flight per wave.  (Issuing the whole weight stream first is slower here:
+// vector loads return in order, so the first activation tile would queue behind all the weights
+// and no MFMA could overlap the stream.)
 template <int NT, int KGW, int MODE>
-__global__ __launch_bounds__(GEMM_THREADS) void rowblock_gemm_kernel(GemmP p) {
-  if (p.ctx->all_done) return;
-  const int step = p.ctx->base + p.step_in_chunk;
-  const int rb = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int b0 = blockIdx.y * (NT * 16);
-  constexpr int KG = KGW * GEMM_WAVES;
-  constexpr int D = KGW < (NT == 1 ? 8 : 6) ? KGW : (NT == 1 ? 8 : 6);
-  __shared__ f32x4 red[GEMM_WAVES][NT][64];
+struct GemmOp {
+  typedef GemmP P;
+  static __device__ __forceinline__ void run(const GemmP& p, int wg) {
+    const int done = p.ctx->all_done;
+    const int rb = p.rb0 + wg % p.nrb, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b0 = (wg / p.nrb) * (NT * 16);
+    constexpr int D = KGW < (NT == 1 ? 8 : 6) ? KGW : (NT == 1 ? 8 : 6);
+    __shared__ f32x4 red[GEMM_WAVES][NT][64];
 
-  f32x4 acc[NT];
+    const float4* W = reinterpret_cast<const float4*>(p.Wp) + ((size_t)rb * p.kg_stride + p.kg0 + wave) * 64 + lane;
+    // activation pointers of the (up to three) segments, positioned at this lane's quad row / column
+    const size_t xoff = (size_t)(lane >> 4) * p.Bpad + b0 + (lane & 15);
+    const float4* X0 = reinterpret_cast<const float4*>(seg_ptr(p.seg[0], p.parity)) + xoff;
+    const float4* X1 = p.nseg > 1 ? reinterpret_cast<const float4*>(seg_ptr(p.seg[1], p.parity)) + xoff : X0;
+    const float4* X2 = p.nseg > 2 ? reinterpret_cast<const float4*>(seg_ptr(p.seg[2], p.parity)) + xoff : X0;
+    const int e0 = p.seg[0].kgroups, e1 = e0 + (p.nseg > 1 ? p.seg[1].kgroups : 0);
+    const size_t xs = (size_t)4 * p.Bpad;  // float4 stride between k-groups
+    auto xptr = [&](int g) -> const float4* {
+      return g < e0 ? X0 + (size_t)g * xs : (g < e1 ? X1 + (size_t)(g - e0) * xs : X2 + (size_t)(g - e1) * xs);
+    };
+    float4 wv[D], xv[D][NT];
 #pragma unroll
-  for (int n = 0; n < NT; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  const float4* W = reinterpret_cast<const float4*>(p.Wp) + ((size_t)rb * KG + wave) * 64 + lane;
-  // activation pointers of the (up to three) segments, positioned at this lane's quad row / column
-  const size_t xoff = (size_t)(lane >> 4) * p.Bpad + b0 + (lane & 15);
-  const float4* X0 = reinterpret_cast<const float4*>(seg_ptr(p.seg[0], step)) + xoff;
-  const float4* X1 = p.nseg > 1 ? reinterpret_cast<const float4*>(seg_ptr(p.seg[1], step)) + xoff : X0;
-  const float4* X2 = p.nseg > 2 ? reinterpret_cast<const float4*>(seg_ptr(p.seg[2], step)) + xoff : X0;
-  const int e0 = p.seg[0].kgroups, e1 = e0 + (p.nseg > 1 ? p.seg[1].kgroups : 0);
-  const size_t xs = (size_t)4 * p.Bpad;  // float4 stride between k-groups
-  auto xptr = [&](int g) -> const float4* {
-    return g < e0 ? X0 + (size_t)g * xs : (g < e1 ? X1 + (size_t)(g - e0) * xs : X2 + (size_t)(g - e1) * xs);
-  };
-
-  float4 wv[D], xv[D][NT];
+    for (int i = 0; i < D; ++i) {
+      wv[i] = W[(size_t)i * GEMM_WAVES * 64];
+      const float4* xp = xptr(wave + i * GEMM_WAVES);
 #pragma unroll
-  for (int i = 0; i < D; ++i) {
-    wv[i] = W[(size_t)i * GEMM_WAVES * 64];
-    const float4* xp = xptr(wave + i * GEMM_WAVES);
-#pragma unroll
-    for (int n = 0; n < NT; ++n) xv[i][n] = xp[n * 16];
-  }
-#pragma unroll
-  for (int i = 0; i < KGW; ++i) {
-    const int sl = i % D;
-#pragma unroll
-    for (int n = 0; n < NT; ++n) {
-      acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[sl].x, xv[sl][n].x, acc[n], 0, 0, 0);
-      acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[sl].y, xv[sl][n].y, acc[n], 0, 0, 0);
-      acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[sl].z, xv[sl][n].z, acc[n], 0, 0, 0);
-      acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[sl].w, xv[sl][n].w, acc[n], 0, 0, 0);
+      for (int n = 0; n < NT; ++n) xv[i][n] = xp[n * 16];
     }
-    if (i + D < KGW) {
-      wv[sl] = W[(size_t)(i + D) * GEMM_WAVES * 64];
-      const float4* xp = xptr(wave + (i + D) * GEMM_WAVES);
-#pragma unroll
-      for (int n = 0; n < NT; ++n) xv[sl][n] = xp[n * 16];
-    }
-  }
-#pragma unroll
-  for (int n = 0; n < NT; ++n) red[wave][n][lane] = acc[n];
-  __syncthreads();
-
-  // wave w finishes n-tile w: lane l holds rows 4*(l>>4)+{0..3} of column l&15
-  for (int n = wave; n < NT; n += GEMM_WAVES) {
-    f32x4 v = red[0][n][lane];
-#pragma unroll
-    for (int w = 1; w < GEMM_WAVES; ++w) v += red[w][n][lane];
-    const int b = b0 + n * 16 + (lane & 15);
+    // epilogue operands of the n-tile(s) this wave finishes
     const int quad = rb * 4 + (lane >> 4);
-    const float4 bias = reinterpret_cast<const float4*>(p.bias)[quad];
-    v[0] += bias.x, v[1] += bias.y, v[2] += bias.z, v[3] += bias.w;
-    epilogue_quad<MODE>(p, step, quad, b, v);
+    Pre pre[(NT + GEMM_WAVES - 1) / GEMM_WAVES];
+#pragma unroll
+    for (int k = 0; k < (NT + GEMM_WAVES - 1) / GEMM_WAVES; ++k) {
+      const int n = wave + k * GEMM_WAVES;
+      if (n < NT) pre[k] = prefetch_quad<MODE>(p, quad, b0 + n * 16 + (lane & 15));
+    }
+
+    f32x4 acc[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < KGW; ++i) {
+      const int sl = i % D;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[sl].x, xv[sl][n].x, acc[n], 0, 0, 0);
+        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[sl].y, xv[sl][n].y, acc[n], 0, 0, 0);
+        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[sl].z, xv[sl][n].z, acc[n], 0, 0, 0);
+        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[sl].w, xv[sl][n].w, acc[n], 0, 0, 0);
+      }
+      if (i + D < KGW) {
+        wv[sl] = W[(size_t)(i + D) * GEMM_WAVES * 64];
+        const float4* xp = xptr(wave + (i + D) * GEMM_WAVES);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) xv[sl][n] = xp[n * 16];
+      }
+    }
+#pragma unroll
+    for (int n = 0; n < NT; ++n) red[wave][n][lane] = acc[n];
+    __syncthreads();
+    if (done) return;
+
+    // wave w finishes n-tile w: lane l holds rows 4*(l>>4)+{0..3} of column l&15
+#pragma unroll
+    for (int k = 0; k < (NT + GEMM_WAVES - 1) / GEMM_WAVES; ++k) {
+      const int n = wave + k * GEMM_WAVES;
+      if (n >= NT) break;
+      f32x4 v = red[0][n][lane];
+#pragma unroll
+      for (int w = 1; w < GEMM_WAVES; ++w) v += red[w][n][lane];
+      epilogue_quad<MODE>(p, quad, b0 + n * 16 + (lane & 15), v, pre[k]);
+    }
   }
-}
+};
 
 // GEMV engine for NB <= 2 utterances (Bpad == NB): every weight load of a wave is issued before
 // the first use, activations come from LDS.  KGW = k-groups per wave (KG / 8).
 template <int NB, int KGW, int MODE>
-__global__ __launch_bounds__(GEMM_THREADS) void rowblock_gemv_kernel(GemmP p) {
-  if (p.ctx->all_done) return;
-  const int step = p.ctx->base + p.step_in_chunk;
-  const int rb = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, tid = threadIdx.x;
-  constexpr int KG = KGW * GEMM_WAVES;
-  __shared__ float4 s_x[KG * 4 * NB];  // quad-interleaved: [quad][b]
-  __shared__ float s_red[GEMM_WAVES][NB][16];
+struct GemvOp {
+  typedef GemmP P;
+  static __device__ __forceinline__ void run(const GemmP& p, int wg) {
+    const int done = p.ctx->all_done;
+    const int rb = p.rb0 + wg, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, tid = threadIdx.x;
+    constexpr int KG = KGW * GEMM_WAVES;
+    __shared__ float4 s_x[KG * 4 * NB];  // quad-interleaved: [quad][b]
+    __shared__ float s_red[GEMM_WAVES][NB][16];
 
-  // issue the weight stream first
-  const float4* W = reinterpret_cast<const float4*>(p.Wp) + (size_t)rb * KG * 64 + lane;
-  float4 wv[KGW];
+    // issue the weight stream first
+    const float4* W = reinterpret_cast<const float4*>(p.Wp) + ((size_t)rb * p.kg_stride + p.kg0) * 64 + lane;
+    float4 wv[KGW];
 #pragma unroll
-  for (int i = 0; i < KGW; ++i) {
-#ifdef TTSX_NT_WEIGHTS
-    wv[i] = __builtin_nontemporal_load(W + (size_t)(wave + i * GEMM_WAVES) * 64);
-#else
-    wv[i] = W[(size_t)(wave + i * GEMM_WAVES) * 64];
-#endif
-  }
+    for (int i = 0; i < KGW; ++i) wv[i] = W[(size_t)(wave + i * GEMM_WAVES) * 64];
 
-  // stage the activations (segments are already quad-interleaved with Bpad == NB)
-  {
-    int q0 = 0;
-    for (int s = 0; s < p.nseg; ++s) {
-      const Seg sg = p.seg[s];
-      const float4* X = reinterpret_cast<const float4*>(seg_ptr(sg, step));
-      const int n = sg.kgroups * 4 * NB;
-      for (int i = tid; i < n; i += GEMM_THREADS) s_x[q0 + i] = X[i];
-      q0 += n;
+    // stage the activations (segments are already quad-interleaved with Bpad == NB)
+    {
+      int q0 = 0;
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        if (s < p.nseg) {
+          const float4* X = reinterpret_cast<const float4*>(seg_ptr(p.seg[s], p.parity));
+          const int n = p.seg[s].kgroups * 4 * NB;
+          for (int i = tid; i < n; i += GEMM_THREADS) s_x[q0 + i] = X[i];
+          q0 += n;
+        }
+      }
     }
-  }
-  __syncthreads();
+    // epilogue operands: thread (qi, b) finishes quad qi of the row block for utterance b
+    const int qi = tid / NB, eb = tid % NB, quad_e = rb * 4 + qi;
+    Pre pre;
+    if (tid < 4 * NB) pre = prefetch_quad<MODE>(p, quad_e, eb);
+    __syncthreads();
 
-  float acc[NB];
+    float acc[NB];
 #pragma unroll
-  for (int b = 0; b < NB; ++b) acc[b] = 0.f;
-  const int kq = lane >> 4;
+    for (int b = 0; b < NB; ++b) acc[b] = 0.f;
+    const int kq = lane >> 4;
 #pragma unroll
-  for (int i = 0; i < KGW; ++i) {
-    const int quad = (wave + i * GEMM_WAVES) * 4 + kq;
+    for (int i = 0; i < KGW; ++i) {
+      const int quad = (wave + i * GEMM_WAVES) * 4 + kq;
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const float4 xv = s_x[quad * NB + b];
+        acc[b] += wv[i].x * xv.x + wv[i].y * xv.y + wv[i].z * xv.z + wv[i].w * xv.w;
+      }
+    }
+    // lanes l, l^16, l^32, l^48 hold partial sums of the same row
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
-      const float4 xv = s_x[quad * NB + b];
-      acc[b] += wv[i].x * xv.x + wv[i].y * xv.y + wv[i].z * xv.z + wv[i].w * xv.w;
+      acc[b] += __shfl_xor(acc[b], 16, 64);
+      acc[b] += __shfl_xor(acc[b], 32, 64);
+      if (lane < 16) s_red[wave][b][lane] = acc[b];
+    }
+    __syncthreads();
+    if (done) return;
+    if (tid < 4 * NB) {
+      f32x4 v;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < GEMM_WAVES; ++w) t += s_red[w][eb][qi * 4 + j];
+        v[j] = t;
+      }
+      epilogue_quad<MODE>(p, quad_e, eb, v, pre);
     }
   }
-  // lanes l, l^16, l^32, l^48 hold partial sums of the same row
-#pragma unroll
-  for (int b = 0; b < NB; ++b) {
-    acc[b] += __shfl_xor(acc[b], 16, 64);
-    acc[b] += __shfl_xor(acc[b], 32, 64);
-    if (lane < 16) s_red[wave][b][lane] = acc[b];
-  }
-  __syncthreads();
-  if (tid < 4 * NB) {
-    const int qi = tid / NB, b = tid % NB;  // quad inside the row block, utterance
-    const int quad = rb * 4 + qi;
-    f32x4 v;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float t = 0.f;
-#pragma unroll
-      for (int w = 0; w < GEMM_WAVES; ++w) t += s_red[w][b][qi * 4 + j];
-      v[j] = t;
-    }
-    const float4 bias = reinterpret_cast<const float4*>(p.bias)[quad];
-    v[0] += bias.x, v[1] += bias.y, v[2] += bias.z, v[3] += bias.w;
-    epilogue_quad<MODE>(p, step, quad, b, v);
-  }
+};
+
+// Nothing: the second slot of a launch that carries no partial piece.
+struct NoOp {
+  typedef int P;
+  static __device__ __forceinline__ void run(const int&, int) {}
+};
+
+// A launch: workgroups [0, n_first) run op A (the one on the serial path, scheduled first), the
+// rest run op B (a piece of partial LSTM work).
+template <class A, class B>
+__global__ __launch_bounds__(GEMM_THREADS) void dual_kernel(typename A::P pa, typename B::P pb, int n_first) {
+  if ((int)blockIdx.x < n_first) A::run(pa, blockIdx.x);
+  else B::run(pb, blockIdx.x - n_first);
 }
 
 // ------------------------------------------------------------------ attention
@@ -380,11 +454,14 @@ struct AttnP {
   float* a_cum;          // [B][T]
   float* energies;       // [B][T]
   float* ctx_out;        // quad [512]
+  const float* enc;      // [B][T][512] encoder outputs (the decoder's own copy: a stable address)
+  const int32_t* len;    // [B] valid encoder positions per utterance
   RunCtx* ctx;
-  int step_in_chunk, Bpad, norm;
+  int step_in_chunk, Bpad, norm, T;
+  int gx;  // workgroups per utterance: workgroup id = b * gx + x
 };
 
-constexpr int EN_TT = 32, EN_THREADS = 512, ATT_PAD = (LOC_K - 1) / 2;
+constexpr int EN_TT = 32, ATT_PAD = (LOC_K - 1) / 2;
 
 // tanh through one hardware exponential: 1 - 2/(e^{2x}+1); saturates correctly at +-inf
 __device__ __forceinline__ float fast_tanhf(float x) {
@@ -397,10 +474,11 @@ __device__ __forceinline__ float fast_tanhf(float x) {
 //   e[t] = b_v + sum_d v[d] * tanh(q[d] + sum_f W_ld[d][f] cf[t][f] + P[t][d])   (thread: dim d, 8 positions)
 // Every global load of the kernel is issued before the first barrier, so the whole kernel costs
 // one memory round trip.
-__global__ __launch_bounds__(EN_THREADS) void energy_kernel(AttnP p) {
-  const RunCtx* cx = p.ctx;
-  if (cx->all_done) return;
-  const int T = cx->T, b = blockIdx.y, t0 = blockIdx.x * EN_TT, tid = threadIdx.x;
+struct EnergyOp {
+  typedef AttnP P;
+  static __device__ __forceinline__ void run(const AttnP& p, int wg) {
+  const int done = p.ctx->all_done;
+  const int T = p.T, b = wg / p.gx, t0 = (wg % p.gx) * EN_TT, tid = threadIdx.x;
   __shared__ float s_a[2][EN_TT + 2 * ATT_PAD + 2];
   __shared__ __attribute__((aligned(16))) float s_cf[EN_TT][LOC_F];
   __shared__ float s_part[2][EN_TT];
@@ -469,29 +547,33 @@ __global__ __launch_bounds__(EN_THREADS) void energy_kernel(AttnP p) {
     if ((tid & 63) == 0) s_part[(tid >> 6) & 1][tl] = e;
   }
   __syncthreads();
-  if (tid < EN_TT && t0 + tid < T) p.energies[(size_t)b * T + t0 + tid] = s_part[0][tid] + s_part[1][tid] + vb;
-}
+  if (!done && tid < EN_TT && t0 + tid < T)
+    p.energies[(size_t)b * T + t0 + tid] = s_part[0][tid] + s_part[1][tid] + vb;
+  }
+};
 
 // normalisation over the encoder axis (every workgroup of an utterance repeats it: T exps) and a
 // slice of CW context columns: ctx[c] = sum_t a[t] enc[t][c].  Workgroup x == 0 also writes the
 // alignment outputs and the location-attention state.  The first CTX_PRE rows of encoder outputs
 // a thread needs are loaded before the normalisation, so that round trip overlaps it.
-constexpr int CTX_PRE = 16;
+constexpr int CTX_PRE = 8, CTX_THREADS = GEMM_THREADS;
 template <int CW>
-__global__ __launch_bounds__(256) void context_kernel(AttnP p) {
+struct ContextOp {
+  typedef AttnP P;
+  static __device__ __forceinline__ void run(const AttnP& p, int wg) {
   RunCtx* cx = p.ctx;
-  if (cx->all_done) return;
-  const int T = cx->T, b = blockIdx.y, tid = threadIdx.x;
-  const int len = cx->enc_len ? cx->enc_len[b] : T;
+  const int done = cx->all_done;
+  const int T = p.T, b = wg / p.gx, bx = wg % p.gx, tid = threadIdx.x;
+  const int len = p.len[b];
   extern __shared__ float s_dyn[];
   float* s_al = s_dyn;  // [T]
-  __shared__ float s_red[4];
-  __shared__ float4 s_acc[256];
+  __shared__ float s_red[CTX_THREADS / 64];
+  __shared__ float4 s_acc[CTX_THREADS];
 
   // context slice geometry: lane group = CW/4 float4 columns, row groups stride over t
-  constexpr int LPR = CW / 4, RG = 256 / LPR;
+  constexpr int LPR = CW / 4, RG = CTX_THREADS / LPR;
   const int cl = tid % LPR, rg = tid / LPR;
-  const float4* e4 = reinterpret_cast<const float4*>(cx->enc + (size_t)b * T * ENC_DIM + blockIdx.x * CW) + cl;
+  const float4* e4 = reinterpret_cast<const float4*>(p.enc + (size_t)b * T * ENC_DIM + bx * CW) + cl;
   float4 pre[CTX_PRE];
 #pragma unroll
   for (int i = 0; i < CTX_PRE; ++i) {
@@ -502,15 +584,17 @@ __global__ __launch_bounds__(256) void context_kernel(AttnP p) {
   const bool softmax = p.norm == TTSX_NORM_SOFTMAX;
   float m = -INFINITY;
   if (softmax) {
-    for (int t = tid; t < len; t += 256) m = fmaxf(m, p.energies[(size_t)b * T + t]);
+    for (int t = tid; t < len; t += CTX_THREADS) m = fmaxf(m, p.energies[(size_t)b * T + t]);
     m = wave_max(m);
     if ((tid & 63) == 0) s_red[tid >> 6] = m;
     __syncthreads();
-    m = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+    m = s_red[0];
+#pragma unroll
+    for (int w = 1; w < CTX_THREADS / 64; ++w) m = fmaxf(m, s_red[w]);
     __syncthreads();
   }
   float sum = 0.f;
-  for (int t = tid; t < T; t += 256) {
+  for (int t = tid; t < T; t += CTX_THREADS) {
     float v = 0.f;
     if (t < len) {
       const float e = p.energies[(size_t)b * T + t];
@@ -522,13 +606,14 @@ __global__ __launch_bounds__(256) void context_kernel(AttnP p) {
   sum = wave_sum(sum);
   if ((tid & 63) == 0) s_red[tid >> 6] = sum;
   __syncthreads();
-  sum = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
-  for (int t = tid; t < T; t += 256) s_al[t] = s_al[t] / sum;
+  sum = ((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) + ((s_red[4] + s_red[5]) + (s_red[6] + s_red[7]));
+  for (int t = tid; t < T; t += CTX_THREADS) s_al[t] = s_al[t] / sum;
   __syncthreads();
+  if (done) return;
 
-  if (blockIdx.x == 0) {
+  if (bx == 0) {
     const int row = cx->out_base + p.step_in_chunk;
-    for (int t = tid; t < T; t += 256) {
+    for (int t = tid; t < T; t += CTX_THREADS) {
       const float a = s_al[t];
       p.a_prev[(size_t)b * T + t] = a;
       p.a_cum[(size_t)b * T + t] += a;
@@ -555,10 +640,11 @@ __global__ __launch_bounds__(256) void context_kernel(AttnP p) {
       const float4 v = s_acc[g * LPR + tid];
       tot.x += v.x, tot.y += v.y, tot.z += v.z, tot.w += v.w;
     }
-    const int quad = blockIdx.x * LPR + tid;
+    const int quad = bx * LPR + tid;
     reinterpret_cast<float4*>(p.ctx_out)[(size_t)quad * p.Bpad + b] = tot;
   }
-}
+  }
+};
 
 // processed_inputs P[b][t][d] = sum_c enc[b][t][c] * w_in[d][c]
 // (OriginalAttention.preprocess_inputs, once per utterance).
@@ -618,6 +704,10 @@ __global__ void finalize_steps_kernel(int32_t* n_steps, int B, int steps_launche
   int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b < B && n_steps[b] == 0) n_steps[b] = steps_launched;
 }
+__global__ void fill_len_kernel(int32_t* __restrict__ dst, const int32_t* __restrict__ src, int B, int T) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B) dst[b] = src ? min(max(src[b], 0), T) : T;
+}
 // x1 for the first step: memory = 0, so layer 1 gives relu(bias)
 __global__ void init_x1_kernel(float* __restrict__ x1, const float* __restrict__ b1f, int Bpad) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -648,6 +738,11 @@ struct ttsx_t2_decoder {
   // per-run workspace
   int B, T, Bpad, cap_B, cap_T, ws_gen;
   float *x1, *x2, *ctx, *h_a[2], *c_a, *h_d[2], *c_d, *q, *o, *a_prev, *a_cum, *energies, *P;
+  float* enc_ws;     // [B][T][512] copy of the encoder outputs (kernel arguments must not move between runs)
+  int32_t* len_ws;   // [B] encoder lengths (T where the caller gave none)
+  int parity0;       // decoder steps completed before the launches being enqueued, & 1
+  bool split;        // LSTMs cut into early/late columns with the early part riding along other launches
+  float *g_a, *g_d;  // raw gate sums of the partial LSTM launches, quad layout [4096/4][Bpad] float4
   RunCtx* rc;        // device
   RunCtx* rc_host;   // pinned staging copy
   int* host_flag;    // pinned
@@ -656,7 +751,7 @@ struct ttsx_t2_decoder {
   // cached chunk graph
   hipGraphExec_t graph;
   hipStream_t cap_stream;  // capture-only stream: the caller's stream may be the legacy default stream
-  int g_B, g_T, g_r, g_gen, g_chunk;
+  int g_B, g_T, g_r, g_gen, g_chunk, g_split;
 };
 
 namespace {
@@ -700,11 +795,13 @@ void drop_graph(ttsx_t2_decoder* d) {
 
 void free_workspace(ttsx_t2_decoder* d) {
   float** bufs[] = {&d->x1, &d->x2, &d->ctx, &d->h_a[0], &d->h_a[1], &d->c_a, &d->h_d[0], &d->h_d[1], &d->c_d,
-                    &d->q,  &d->o,  &d->a_prev, &d->a_cum, &d->energies, &d->P};
+                    &d->q,  &d->o,  &d->a_prev, &d->a_cum, &d->energies, &d->P, &d->g_a, &d->g_d, &d->enc_ws};
   for (float** b : bufs) {
     if (*b) (void)hipFree(*b);
     *b = nullptr;
   }
+  if (d->len_ws) (void)hipFree(d->len_ws);
+  d->len_ws = nullptr;
   d->cap_B = d->cap_T = 0;
   drop_graph(d);
 }
@@ -729,12 +826,16 @@ int ensure_workspace(ttsx_t2_decoder* d, int B, int T) {
   }
   rc |= dev_alloc(&d->c_a, QUERY_DIM * cb);
   rc |= dev_alloc(&d->c_d, DEC_DIM * cb);
+  rc |= dev_alloc(&d->g_a, 4 * QUERY_DIM * cb);
+  rc |= dev_alloc(&d->g_d, 4 * DEC_DIM * cb);
   rc |= dev_alloc(&d->q, ATT_DIM * cb);
   rc |= dev_alloc(&d->o, (size_t)round_up(proj_rows(d), 16) * cb);
   rc |= dev_alloc(&d->a_prev, cb * ct);
   rc |= dev_alloc(&d->a_cum, cb * ct);
   rc |= dev_alloc(&d->energies, cb * ct);
   rc |= dev_alloc(&d->P, cb * ATT_DIM * ct);
+  rc |= dev_alloc(&d->enc_ws, cb * ENC_DIM * ct);
+  rc |= dev_alloc(&d->len_ws, cb);
   if (rc) return TTSX_ERR_HIP;
   d->cap_B = Bpad, d->cap_T = T, d->Bpad = Bpad;
   d->ws_gen += 1;
@@ -766,101 +867,209 @@ int ensure_proj(ttsx_t2_decoder* d, int r, hipStream_t st) {
   return TTSX_OK;
 }
 
-template <int MODE>
-int launch_gemm(const ttsx_t2_decoder* d, const GemmP& p, int nrb, bool split_n, hipStream_t st) {
-  const int B = d->B;
-  if (B <= GEMV_MAX_B) {
-    dim3 grid(nrb);
-#define TTSX_GEMV(NB, KGW) rowblock_gemv_kernel<NB, KGW, MODE><<<grid, GEMM_THREADS, 0, st>>>(p)
-#define TTSX_GEMV_NB(KGW)       \
-  switch (B) {                  \
-    case 1: TTSX_GEMV(1, KGW); break; \
-    default: TTSX_GEMV(2, KGW); break; \
+// A piece of partial LSTM work: row blocks [rb0, rb0+nrb) of the launch described by `g`.
+struct Piece {
+  GemmP g;
+  bool on;
+};
+
+// The two partial launches of a step, each cut into three pieces by row blocks.
+struct Partial {
+  GemmP g;
+  int total_rb;
+  Piece piece(int k) const {
+    // cuts at 1/3 and 2/3 of the row blocks
+    Piece pc{g, true};
+    const int lo = total_rb * k / 3, hi = total_rb * (k + 1) / 3;
+    pc.g.rb0 = lo, pc.g.nrb = hi - lo;
+    return pc;
   }
-    switch (p.KG) {
-      case 16: TTSX_GEMV_NB(2); break;    // prenet layer 2 (K=256)
-      case 64: TTSX_GEMV_NB(8); break;    // query (K=1024)
-      case 96: TTSX_GEMV_NB(12); break;   // projection (K=1536)
-      case 112: TTSX_GEMV_NB(14); break;  // attention LSTM (K=1792)
-      case 160: TTSX_GEMV_NB(20); break;  // decoder LSTM (K=2560)
-      default:
-        ttsx_set_error("launch_gemm: no GEMV instance for KG=%d", p.KG);
-        return TTSX_ERR_ARG;
-    }
-#undef TTSX_GEMV_NB
-#undef TTSX_GEMV
+};
+
+int n_col_tiles(const ttsx_t2_decoder* d, bool split_n, int* nt) {
+  // column tiles per workgroup: 2 for the big (weight-streaming) GEMMs when the batch allows,
+  // 1 for the small ones, which need the extra workgroups more than the weight reuse
+  const int nt_total = d->Bpad / 16;
+  *nt = (!split_n && nt_total % 2 == 0) ? 2 : 1;
+  return nt_total / *nt;
+}
+
+// Launch op A (params pa, na workgroups, extra dynamic LDS `smem`) together with a partial piece.
+// PK = k-groups per wave of the partial piece (12: attention LSTM, 16: decoder LSTM).
+template <class A, int PK>
+int launch_with_piece(const ttsx_t2_decoder* d, const typename A::P& pa, int na, size_t smem, const Piece* pc,
+                      hipStream_t st) {
+  if (!pc || !pc->on) {
+    dual_kernel<A, NoOp><<<na, GEMM_THREADS, smem, st>>>(pa, 0, na);
+  } else if (d->B <= GEMV_MAX_B) {
+    const int nb = pc->g.nrb;
+    if (d->B == 1) dual_kernel<A, GemvOp<1, PK, MODE_PARTIAL>><<<na + nb, GEMM_THREADS, smem, st>>>(pa, pc->g, na);
+    else dual_kernel<A, GemvOp<2, PK, MODE_PARTIAL>><<<na + nb, GEMM_THREADS, smem, st>>>(pa, pc->g, na);
   } else {
-    // column tiles per workgroup: 2 for the big (weight-streaming) GEMMs when the batch allows,
-    // 1 for the small ones, which need the extra workgroups more than the weight reuse
-    const int nt_total = p.Bpad / 16;
-    const int nt = (!split_n && nt_total % 2 == 0) ? 2 : 1;
-    dim3 grid(nrb, nt_total / nt);
-#define TTSX_GEMM(KGW)                                                                    \
-  if (nt == 2) rowblock_gemm_kernel<2, KGW, MODE><<<grid, GEMM_THREADS, 0, st>>>(p);      \
-  else rowblock_gemm_kernel<1, KGW, MODE><<<grid, GEMM_THREADS, 0, st>>>(p)
-    switch (p.KG) {
-      case 16: TTSX_GEMM(2); break;
-      case 64: TTSX_GEMM(8); break;
-      case 96: TTSX_GEMM(12); break;
-      case 112: TTSX_GEMM(14); break;
-      case 160: TTSX_GEMM(20); break;
-      default:
-        ttsx_set_error("launch_gemm: no GEMM instance for KG=%d", p.KG);
-        return TTSX_ERR_ARG;
-    }
-#undef TTSX_GEMM
+    int nt;
+    const int tiles = n_col_tiles(d, false, &nt);
+    const int nb = pc->g.nrb * tiles;
+    if (nt == 2) dual_kernel<A, GemmOp<2, PK, MODE_PARTIAL>><<<na + nb, GEMM_THREADS, smem, st>>>(pa, pc->g, na);
+    else dual_kernel<A, GemmOp<1, PK, MODE_PARTIAL>><<<na + nb, GEMM_THREADS, smem, st>>>(pa, pc->g, na);
   }
   TTSX_LAUNCH_CHECK();
   return TTSX_OK;
 }
 
-// Enqueue one decoder step; `i` is the step's index inside the current chunk.
-int enqueue_step(ttsx_t2_decoder* d, int i, hipStream_t st) {
-  const int Bpad = d->Bpad, B = d->B, T = d->T;
+// A GEMM/GEMV launch on the serial path (`g` covers all `nrb` row blocks) with an optional piece.
+// KGW = k-groups per wave of the main op.
+template <int MODE, int KGW, int PK>
+int launch_gemm(const ttsx_t2_decoder* d, GemmP g, int nrb, bool split_n, const Piece* pc, hipStream_t st) {
+  g.rb0 = 0, g.nrb = nrb;
+  if (d->B <= GEMV_MAX_B) {
+    if (d->B == 1) return launch_with_piece<GemvOp<1, KGW, MODE>, PK>(d, g, nrb, 0, pc, st);
+    return launch_with_piece<GemvOp<2, KGW, MODE>, PK>(d, g, nrb, 0, pc, st);
+  }
+  int nt;
+  const int tiles = n_col_tiles(d, split_n, &nt);
+  if (nt == 2) return launch_with_piece<GemmOp<2, KGW, MODE>, PK>(d, g, nrb * tiles, 0, pc, st);
+  return launch_with_piece<GemmOp<1, KGW, MODE>, PK>(d, g, nrb * tiles, 0, pc, st);
+}
+
+constexpr int KG1 = (PRENET_DIM + ENC_DIM + QUERY_DIM) / 16, KG2 = (ENC_DIM + QUERY_DIM + DEC_DIM) / 16;
+constexpr int PK1 = (ENC_DIM + QUERY_DIM) / 16 / GEMM_WAVES, PK2 = (QUERY_DIM + DEC_DIM) / 16 / GEMM_WAVES;
+
+// Dynamic LDS (the alignment row, T floats) above the default limit: raise it on every launch
+// variant that carries the context op.
+template <class B>
+hipError_t set_context_lds_for(size_t bytes) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dual_kernel<ContextOp<128>, B>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(dual_kernel<ContextOp<32>, B>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+hipError_t set_context_lds(size_t bytes) {
+  hipError_t e;
+  if ((e = set_context_lds_for<NoOp>(bytes)) != hipSuccess) return e;
+  if ((e = set_context_lds_for<GemvOp<1, PK2, MODE_PARTIAL>>(bytes)) != hipSuccess) return e;
+  if ((e = set_context_lds_for<GemvOp<2, PK2, MODE_PARTIAL>>(bytes)) != hipSuccess) return e;
+  if ((e = set_context_lds_for<GemmOp<1, PK2, MODE_PARTIAL>>(bytes)) != hipSuccess) return e;
+  return set_context_lds_for<GemmOp<2, PK2, MODE_PARTIAL>>(bytes);
+}
+
+// Early columns of the attention LSTM, [ctx(t-1); h_a(t-1)] -> g_a, for the step with chunk index i.
+Partial partial_attn(const ttsx_t2_decoder* d, int i) {
   GemmP g{};
-  g.Bpad = Bpad, g.ctx = d->rc, g.step_in_chunk = i;
+  g.Bpad = d->Bpad, g.ctx = d->rc, g.step_in_chunk = i, g.parity = (d->parity0 + i) & 1;
+  g.Wp = d->w_lstm1, g.nseg = 2, g.KG = (ENC_DIM + QUERY_DIM) / 16, g.kg0 = PRENET_DIM / 16, g.kg_stride = KG1;
+  g.gates = d->g_a;
+  g.seg[0] = Seg{{d->ctx, nullptr}, 0, ENC_DIM / 16};
+  g.seg[1] = Seg{{d->h_a[0], d->h_a[1]}, 1, QUERY_DIM / 16};
+  return Partial{g, QUERY_DIM / 4};
+}
+// Early columns of the decoder LSTM, [h_a(t); h_d(t-1)] -> g_d.
+Partial partial_dec(const ttsx_t2_decoder* d, int i) {
+  GemmP g{};
+  g.Bpad = d->Bpad, g.ctx = d->rc, g.step_in_chunk = i, g.parity = (d->parity0 + i) & 1;
+  g.Wp = d->w_lstm2, g.nseg = 2, g.KG = (QUERY_DIM + DEC_DIM) / 16, g.kg0 = ENC_DIM / 16, g.kg_stride = KG2;
+  g.gates = d->g_d;
+  g.seg[0] = Seg{{d->h_a[0], d->h_a[1]}, 2, QUERY_DIM / 16};
+  g.seg[1] = Seg{{d->h_d[0], d->h_d[1]}, 1, DEC_DIM / 16};
+  return Partial{g, DEC_DIM / 4};
+}
+
+// Enqueue one decoder step; `i` is the step's index inside the current chunk.
+//   first: (split mode) the early attention-LSTM columns of this step have not been computed by
+//          the previous step's launches (first step of a chunk, or a single teacher-forced step);
+//   more:  another step follows in this chunk, so its early attention-LSTM columns ride along with
+//          this step's decoder-LSTM and projection launches (and with its own prenet launch).
+int enqueue_step(ttsx_t2_decoder* d, int i, bool first, bool more, hipStream_t st) {
+  const int Bpad = d->Bpad, B = d->B, T = d->T;
+  const bool split = d->split;
+  GemmP g{};
+  g.Bpad = Bpad, g.ctx = d->rc, g.step_in_chunk = i, g.parity = (d->parity0 + i) & 1;
   int rc;
-  // prenet layer 2: x2 = relu(A2f x1 + b2f)
-  g.Wp = d->w_pre2, g.bias = d->b_pre2, g.nseg = 1, g.KG = PRENET_DIM / 16;
+  const Partial pa = partial_attn(d, i), pd = partial_dec(d, i);
+  const Partial pa_next = partial_attn(d, i + 1);  // reads the state this step leaves behind
+  Piece pc{};
+  if (split && first) {
+    // nothing to hide behind yet: the whole partial as a launch of its own
+    pc = Piece{pa.g, true};
+    pc.g.rb0 = 0, pc.g.nrb = pa.total_rb;
+    if ((rc = launch_with_piece<NoOp, PK1>(d, 0, 0, 0, &pc, st))) return rc;
+  }
+  // prenet layer 2: x2 = relu(A2f x1 + b2f)   (+ last third of this step's attention partial)
+  g.Wp = d->w_pre2, g.bias = d->b_pre2, g.nseg = 1, g.KG = PRENET_DIM / 16, g.kg0 = 0, g.kg_stride = g.KG;
   g.seg[0] = Seg{{d->x1, nullptr}, 0, PRENET_DIM / 16};
   g.out[0] = d->x2, g.relu = 1;
-  if ((rc = launch_gemm<MODE_LINEAR>(d, g, PRENET_DIM / 16, true, st))) return rc;
-  // attention LSTM: [x2; ctx; h_a]
-  g.Wp = d->w_lstm1, g.bias = d->b_lstm1, g.nseg = 3, g.KG = (PRENET_DIM + ENC_DIM + QUERY_DIM) / 16;
+  pc = pa.piece(2);
+  pc.on = split && !first;
+  if ((rc = launch_gemm<MODE_LINEAR, 2, PK1>(d, g, PRENET_DIM / 16, true, &pc, st))) return rc;
+  // attention LSTM: [x2; ctx; h_a] (split: late columns [x2] + the partial sums) + cell update
+  g.Wp = d->w_lstm1, g.bias = d->b_lstm1, g.kg0 = 0, g.kg_stride = KG1;
   g.seg[0] = Seg{{d->x2, nullptr}, 0, PRENET_DIM / 16};
   g.seg[1] = Seg{{d->ctx, nullptr}, 0, ENC_DIM / 16};
   g.seg[2] = Seg{{d->h_a[0], d->h_a[1]}, 1, QUERY_DIM / 16};
   g.out[0] = d->h_a[0], g.out[1] = d->h_a[1], g.c = d->c_a, g.relu = 0;
-  if ((rc = launch_gemm<MODE_LSTM>(d, g, QUERY_DIM / 4, false, st))) return rc;
-  // query projection
-  g.Wp = d->w_query, g.bias = d->b_query, g.nseg = 1, g.KG = QUERY_DIM / 16;
+  if (split) {
+    g.nseg = 1, g.KG = PRENET_DIM / 16, g.gates = d->g_a;
+    rc = launch_gemm<MODE_LSTM, 2, PK1>(d, g, QUERY_DIM / 4, false, nullptr, st);
+  } else {
+    g.nseg = 3, g.KG = KG1, g.gates = nullptr;
+    rc = launch_gemm<MODE_LSTM, KG1 / GEMM_WAVES, PK1>(d, g, QUERY_DIM / 4, false, nullptr, st);
+  }
+  if (rc) return rc;
+  // query projection   (+ first third of the decoder partial)
+  g.Wp = d->w_query, g.bias = d->b_query, g.nseg = 1, g.KG = QUERY_DIM / 16, g.kg0 = 0, g.kg_stride = g.KG;
+  g.gates = nullptr;
   g.seg[0] = Seg{{d->h_a[0], d->h_a[1]}, 2, QUERY_DIM / 16};
   g.out[0] = d->q, g.out[1] = nullptr, g.c = nullptr;
-  if ((rc = launch_gemm<MODE_LINEAR>(d, g, ATT_DIM / 16, true, st))) return rc;
-  // attention
+  pc = pd.piece(0);
+  pc.on = split;
+  if ((rc = launch_gemm<MODE_LINEAR, 8, PK2>(d, g, ATT_DIM / 16, true, &pc, st))) return rc;
+  // attention   (+ second and last third of the decoder partial)
   AttnP ap{};
   ap.q = d->q, ap.P = d->P;
   ap.loc_conv_t = d->loc_conv_w, ap.loc_dense_t = d->loc_dense_w, ap.v_w = d->v_w, ap.v_b = d->v_b;
   ap.a_prev = d->a_prev, ap.a_cum = d->a_cum, ap.energies = d->energies, ap.ctx_out = d->ctx;
+  ap.enc = d->enc_ws, ap.len = d->len_ws, ap.T = T;
   ap.ctx = d->rc, ap.step_in_chunk = i, ap.Bpad = Bpad, ap.norm = d->norm;
-  energy_kernel<<<dim3(ceil_div(T, EN_TT), B), EN_THREADS, 0, st>>>(ap);
-  TTSX_LAUNCH_CHECK();
-  if (B >= 16) context_kernel<128><<<dim3(ENC_DIM / 128, B), 256, sizeof(float) * T, st>>>(ap);
-  else context_kernel<32><<<dim3(ENC_DIM / 32, B), 256, sizeof(float) * T, st>>>(ap);
-  TTSX_LAUNCH_CHECK();
-  // decoder LSTM: [h_a(new); ctx; h_d]
-  g.Wp = d->w_lstm2, g.bias = d->b_lstm2, g.nseg = 3, g.KG = (QUERY_DIM + ENC_DIM + DEC_DIM) / 16;
-  g.seg[0] = Seg{{d->h_a[0], d->h_a[1]}, 2, QUERY_DIM / 16};
-  g.seg[1] = Seg{{d->ctx, nullptr}, 0, ENC_DIM / 16};
+  ap.gx = ceil_div(T, EN_TT);
+  pc = pd.piece(1);
+  pc.on = split;
+  if ((rc = launch_with_piece<EnergyOp, PK2>(d, ap, ap.gx * B, 0, &pc, st))) return rc;
+  pc = pd.piece(2);
+  pc.on = split;
+  if (B >= 16) {
+    ap.gx = ENC_DIM / 128;
+    rc = launch_with_piece<ContextOp<128>, PK2>(d, ap, ap.gx * B, sizeof(float) * T, &pc, st);
+  } else {
+    ap.gx = ENC_DIM / 32;
+    rc = launch_with_piece<ContextOp<32>, PK2>(d, ap, ap.gx * B, sizeof(float) * T, &pc, st);
+  }
+  if (rc) return rc;
+  // decoder LSTM: [ctx; h_a(new); h_d] (split: late columns [ctx] + the partial sums) + cell update
+  //   (+ first third of the next attention partial)
+  g.Wp = d->w_lstm2, g.bias = d->b_lstm2, g.kg0 = 0, g.kg_stride = KG2;
+  g.seg[0] = Seg{{d->ctx, nullptr}, 0, ENC_DIM / 16};
+  g.seg[1] = Seg{{d->h_a[0], d->h_a[1]}, 2, QUERY_DIM / 16};
   g.seg[2] = Seg{{d->h_d[0], d->h_d[1]}, 1, DEC_DIM / 16};
   g.out[0] = d->h_d[0], g.out[1] = d->h_d[1], g.c = d->c_d;
-  if ((rc = launch_gemm<MODE_LSTM>(d, g, DEC_DIM / 4, false, st))) return rc;
-  // projection: mel rows, stop row, next step's prenet layer-1 rows
-  g.Wp = d->w_proj, g.bias = d->b_proj, g.nseg = 2, g.KG = (DEC_DIM + ENC_DIM) / 16;
+  pc = pa_next.piece(0);
+  pc.on = split && more;
+  if (split) {
+    g.nseg = 1, g.KG = ENC_DIM / 16, g.gates = d->g_d;
+    rc = launch_gemm<MODE_LSTM, 4, PK1>(d, g, DEC_DIM / 4, false, &pc, st);
+  } else {
+    g.nseg = 3, g.KG = KG2, g.gates = nullptr;
+    rc = launch_gemm<MODE_LSTM, KG2 / GEMM_WAVES, PK1>(d, g, DEC_DIM / 4, false, nullptr, st);
+  }
+  if (rc) return rc;
+  // projection: mel rows, stop row, next step's prenet layer-1 rows   (+ second third)
+  g.Wp = d->w_proj, g.bias = d->b_proj, g.nseg = 2, g.KG = (DEC_DIM + ENC_DIM) / 16, g.kg0 = 0, g.kg_stride = g.KG;
+  g.gates = nullptr;
   g.seg[0] = Seg{{d->h_d[0], d->h_d[1]}, 2, DEC_DIM / 16};
   g.seg[1] = Seg{{d->ctx, nullptr}, 0, ENC_DIM / 16};
   g.out[0] = d->o, g.out[1] = nullptr, g.c = nullptr, g.x1 = d->x1, g.o_quads = d->odim / 4;
-  return launch_gemm<MODE_PROJ>(d, g, ceil_div(proj_rows(d), 16), true, st);
+  pc = pa_next.piece(1);
+  pc.on = split && more;
+  return launch_gemm<MODE_PROJ, 12, PK1>(d, g, ceil_div(proj_rows(d), 16), true, &pc, st);
 }
 
 int push_ctx(ttsx_t2_decoder* d, hipStream_t st) {
@@ -873,14 +1082,14 @@ int push_ctx(ttsx_t2_decoder* d, hipStream_t st) {
 // Launch `n` steps as one graph (captured once per (B, T, r, workspace) and chunk size).
 int launch_chunk(ttsx_t2_decoder* d, int n, hipStream_t st) {
   const bool cached = d->graph && d->g_B == d->B && d->g_T == d->T && d->g_r == d->rc_host->r &&
-                      d->g_gen == d->ws_gen && d->g_chunk == n;
+                      d->g_gen == d->ws_gen && d->g_chunk == n && d->g_split == (int)d->split;
   if (!cached && n == CHUNK) {
     drop_graph(d);
     hipGraph_t graph = nullptr;
     hipStream_t cs = d->cap_stream;
     TTSX_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
     int rc = TTSX_OK;
-    for (int i = 0; i < n && !rc; ++i) rc = enqueue_step(d, i, cs);
+    for (int i = 0; i < n && !rc; ++i) rc = enqueue_step(d, i, i == 0, i + 1 < n, cs);
     if (!rc) ctx_advance_kernel<<<1, 1, 0, cs>>>(d->rc, n);
     hipError_t e = hipStreamEndCapture(cs, &graph);
     if (rc) {
@@ -891,13 +1100,14 @@ int launch_chunk(ttsx_t2_decoder* d, int n, hipStream_t st) {
     TTSX_HIP(hipGraphInstantiate(&d->graph, graph, nullptr, nullptr, 0));
     (void)hipGraphDestroy(graph);
     d->g_B = d->B, d->g_T = d->T, d->g_r = d->rc_host->r, d->g_gen = d->ws_gen, d->g_chunk = n;
+    d->g_split = d->split;
   }
   if (n == CHUNK) {
     TTSX_HIP(hipGraphLaunch(d->graph, st));
     return TTSX_OK;
   }
   for (int i = 0; i < n; ++i) {
-    int rc = enqueue_step(d, i, st);
+    int rc = enqueue_step(d, i, i == 0, i + 1 < n, st);
     if (rc) return rc;
   }
   ctx_advance_kernel<<<1, 1, 0, st>>>(d->rc, n);
@@ -920,7 +1130,13 @@ extern "C" int ttsx_t2_decoder_create(const ttsx_t2_decoder_weights* w, int r_in
   int rc = 0;
   rc |= pack_layer(&d->w_lstm1, &d->b_lstm1, w->attn_rnn_w_ih, PRENET_DIM + ENC_DIM, w->attn_rnn_w_hh, QUERY_DIM,
                    w->attn_rnn_b_ih, w->attn_rnn_b_hh, 4 * QUERY_DIM, QUERY_DIM, st);
-  rc |= pack_layer(&d->w_lstm2, &d->b_lstm2, w->dec_rnn_w_ih, QUERY_DIM + ENC_DIM, w->dec_rnn_w_hh, DEC_DIM,
+  // decoder LSTM columns reordered to [ctx; h_a; h_d] so that the late (context) columns and the
+  // early ones are each one contiguous run of k-groups
+  float* w_ih2 = nullptr;
+  if (dev_alloc(&w_ih2, (size_t)4 * DEC_DIM * (QUERY_DIM + ENC_DIM))) return TTSX_ERR_HIP;
+  swap_cols_kernel<<<4 * DEC_DIM, 256, 0, st>>>(w_ih2, w->dec_rnn_w_ih, QUERY_DIM, ENC_DIM);
+  TTSX_LAUNCH_CHECK();
+  rc |= pack_layer(&d->w_lstm2, &d->b_lstm2, w_ih2, ENC_DIM + QUERY_DIM, w->dec_rnn_w_hh, DEC_DIM,
                    w->dec_rnn_b_ih, w->dec_rnn_b_hh, 4 * DEC_DIM, DEC_DIM, st);
   rc |= pack_layer(&d->w_query, &d->b_query, w->query_w, QUERY_DIM, nullptr, 0, nullptr, nullptr, ATT_DIM, 0, st);
   if (rc) return TTSX_ERR_HIP;
@@ -958,7 +1174,7 @@ extern "C" int ttsx_t2_decoder_create(const ttsx_t2_decoder_weights* w, int r_in
   memset(d->rc_host, 0, sizeof(RunCtx));
   TTSX_HIP(hipStreamCreateWithFlags(&d->cap_stream, hipStreamNonBlocking));
   TTSX_HIP(hipStreamSynchronize(st));
-  (void)hipFree(a2f), (void)hipFree(b2f);
+  (void)hipFree(a2f), (void)hipFree(b2f), (void)hipFree(w_ih2);
   rc = ensure_proj(d, r_init, st);
   if (rc) return rc;
   *out = d;
@@ -990,6 +1206,12 @@ extern "C" int ttsx_t2_decoder_begin(ttsx_t2_decoder* d, const float* enc, const
   int rc = ensure_workspace(d, B, T);
   if (rc) return rc;
   d->B = B, d->T = T;
+  {
+    // early/late LSTM split: pays where the launches are latency-bound (GEMV regime); TTSX_SPLIT=0/1 overrides
+    const char* e = getenv("TTSX_SPLIT");
+    d->split = e ? e[0] == '1' : B <= GEMV_MAX_B;
+  }
+  d->parity0 = 0;
   const size_t cb = d->Bpad;
   TTSX_HIP(hipMemsetAsync(d->x2, 0, sizeof(float) * PRENET_DIM * cb, st));
   TTSX_HIP(hipMemsetAsync(d->ctx, 0, sizeof(float) * ENC_DIM * cb, st));
@@ -1006,17 +1228,16 @@ extern "C" int ttsx_t2_decoder_begin(ttsx_t2_decoder* d, const float* enc, const
   init_x1_kernel<<<ceil_div(PRENET_DIM * (int)cb, 256), 256, 0, st>>>(d->x1, d->b1f, (int)cb);
   TTSX_LAUNCH_CHECK();
   if (sizeof(float) * T > 48 * 1024) {
-    TTSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(context_kernel<32>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * T)));
-    TTSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(context_kernel<128>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * T)));
+    TTSX_HIP(set_context_lds(sizeof(float) * T));
   }
-  inputs_proj_kernel<<<dim3(ceil_div(T, 16), B), 256, 0, st>>>(d->P, enc, d->inputs_w, T);
+  TTSX_HIP(hipMemcpyAsync(d->enc_ws, enc, sizeof(float) * (size_t)B * T * ENC_DIM, hipMemcpyDeviceToDevice, st));
+  fill_len_kernel<<<ceil_div(B, 256), 256, 0, st>>>(d->len_ws, enc_len, B, T);
+  TTSX_LAUNCH_CHECK();
+  inputs_proj_kernel<<<dim3(ceil_div(T, 16), B), 256, 0, st>>>(d->P, d->enc_ws, d->inputs_w, T);
   TTSX_LAUNCH_CHECK();
   RunCtx* h = d->rc_host;
   memset(h, 0, sizeof(*h));
   h->B = B, h->T = T, h->r = d->proj_r, h->threshold = 2.f;
-  h->enc = enc, h->enc_len = enc_len;
   d->steps_done = 0;
   d->begun = true;
   return push_ctx(d, st);
@@ -1106,7 +1327,8 @@ extern "C" int ttsx_t2_decoder_step(ttsx_t2_decoder* d, const float* memory, int
   prenet1_explicit_kernel<<<ceil_div(d->B * PRENET_DIM, 256), 256, 0, st>>>(d->x1, memory, d->a1f, d->b1f, d->B,
                                                                            d->Bpad);
   TTSX_LAUNCH_CHECK();
-  rc = enqueue_step(d, 0, st);
+  d->parity0 = d->steps_done & 1;
+  rc = enqueue_step(d, 0, true, false, st);
   if (rc) return rc;
   d->steps_done += 1;
   return TTSX_OK;
