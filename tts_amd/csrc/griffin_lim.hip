@@ -7,15 +7,17 @@
 // win_length zero-padded centrally to n_fft, overlap-add divided by the window sum-square
 // where it exceeds float32 tiny, n_fft/2 samples trimmed at both ends.
 //
-// Structure of one iteration (two launches):
-//   frame kernel  one WAVE per frame, four frames per workgroup, no workgroup barriers in the
-//                 loop: windowed frame -> 2048-point real FFT (as a 1024-point complex FFT,
-//                 radix 16 x 16 x 4, 16 points per lane in registers, LDS only for the
-//                 transposes between passes) -> unit phasor x target magnitude -> inverse FFT
-//                 -> synthesis window -> windowed frame written to HBM.
-//   ola kernel    streaming overlap-add of the windowed frames (a gather, no atomics, so the
-//                 result is bit-reproducible), window-sum-square normalisation and centre
-//                 padding, producing the padded signal the next frame kernel reads.
+// One Griffin-Lim iteration is ONE launch.  A workgroup owns a run of consecutive frames of one
+// utterance and walks it in rounds of four frames, one WAVE per frame:
+//   windowed frame -> 2048-point real FFT (as a 1024-point complex FFT, radix 16 x 16 x 4,
+//   16 points per lane in registers, LDS only for the transposes between passes) -> unit phasor
+//   x target magnitude -> inverse FFT -> synthesis window -> windowed frame left in LDS;
+// after each round the workgroup overlap-adds the four new frames onto a carry of the previous
+// ones (fixed order, no atomics: bit-reproducible), applies the window-sum-square normalisation
+// and writes hop-sized slots of the next padded signal.  The windowed frames never travel to
+// HBM.  A run starts with "halo" rounds that rebuild the carry of the frames before it.
+// The stand-alone STFT / ISTFT entry points use the same frame code with a separate
+// overlap-add launch.
 #include <math.h>
 
 #include <mutex>
@@ -29,6 +31,7 @@ constexpr int NFFT = 2048, MC = 1024, NBIN = 1025;
 constexpr int WP = 1104;          // row pitch of the windowed-frame buffer (floats)
 constexpr int FR_PER_WG = 4;      // frames (waves) per workgroup
 constexpr int LDS_PER_FR = MC + MC / 16;  // float2 per frame, padded by one every 16 against bank conflicts
+constexpr int OLA_MAXK = 8;       // frames that can overlap one sample: ceil(win / hop) <= 8
 
 struct Tables {
   float2* tw;    // W_2048^m = exp(-2 pi i m / 2048), m = 0..1023
@@ -170,28 +173,24 @@ struct FrameP {
   FrameGeom q;
 };
 
-template <int KIND>
-__global__ __launch_bounds__(64 * FR_PER_WG, 3) void frame_kernel(FrameP p) {
-  __shared__ float2 s_tw[1024];   // W_1024^m
-  __shared__ float2 s_tw2[516];   // W_2048^k, k <= 512 (real-transform post/pre-processing)
-  __shared__ float2 s_data[FR_PER_WG][LDS_PER_FR];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+__device__ __forceinline__ void load_tables(float2* s_tw, float2* s_tw2, const float2* tw, int tid) {
   for (int i = tid; i < 1024; i += 64 * FR_PER_WG) {
-    const float2 w = p.tw[(2 * i) & 1023];  // W_1024^i = W_2048^(2i), and W_1024^(i+512) = -W_1024^i
+    const float2 w = tw[(2 * i) & 1023];  // W_1024^i = W_2048^(2i), and W_1024^(i+512) = -W_1024^i
     s_tw[i] = i >= 512 ? make_float2(-w.x, -w.y) : w;
   }
-  for (int i = tid; i <= 512; i += 64 * FR_PER_WG) s_tw2[i] = p.tw[i];
-  __syncthreads();
-  const FrameGeom q = p.q;
-  const long total = (long)p.B * p.F;
-  float2* s = s_data[wave];
-  // the padded window (8 KiB) stays L1-resident: read it through the vector cache, not LDS
-  const float2* s_win2 = reinterpret_cast<const float2*>(p.winpad);
+  for (int i = tid; i <= 512; i += 64 * FR_PER_WG) s_tw2[i] = tw[i];
+}
 
-  for (long fi = (long)blockIdx.x * FR_PER_WG + wave; fi < total; fi += (long)gridDim.x * FR_PER_WG) {
-    const int b = (int)(fi / p.F), i = (int)(fi % p.F);
-    const int Fb = p.n_frames ? p.n_frames[b] : p.F;
-    if (i >= Fb) continue;  // wave-uniform
+// One frame (utterance b, frame i) by one wave.  `s` is the wave's LDS region.  TO_LDS: the
+// windowed synthesis frame (samples lpad_even .. lpad_even + WP of the frame) is left in the
+// wave's own region, viewed as floats, instead of being written to yw_out.
+template <int KIND, bool TO_LDS>
+__device__ __forceinline__ void frame_body(const FrameP& p, int b, int i, float2* s, const float2* s_tw,
+                                           const float2* s_tw2, int lane) {
+  {
+    const FrameGeom q = p.q;
+    // the padded window (8 KiB) stays L1-resident: read it through the vector cache, not LDS
+    const float2* s_win2 = reinterpret_cast<const float2*>(p.winpad);
     const size_t frow = (size_t)b * p.F + i;
     float2 v[16];
     int z = 0;
@@ -201,6 +200,17 @@ __global__ __launch_bounds__(64 * FR_PER_WG, 3) void frame_kernel(FrameP p) {
     int lane_a = lane, lane_b = lane, lane_s = lane;
     asm volatile("" : "+v"(lane_a), "+v"(lane_b), "+v"(lane_s));
 
+    // target magnitudes of this lane's bin pairs, requested now so that they land during the analysis FFT
+    float mk[8], mm[8], m512 = 0.f;
+    if (KIND == K_GL_ITER) {
+      const float* mg0 = p.mag + frow * NBIN;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        mk[c] = mg0[lane_a + 64 * c];
+        mm[c] = mg0[MC - (lane_a + 64 * c)];
+      }
+      m512 = mg0[MC / 2];
+    }
     if (KIND == K_GL_ITER || KIND == K_STFT) {
       // ---- analysis: z[m] = (x[2m], x[2m+1]) windowed, first radix-16 pass straight from HBM
       const float* src = p.ypad + (size_t)b * q.LP + (size_t)i * q.hop;
@@ -230,7 +240,7 @@ __global__ __launch_bounds__(64 * FR_PER_WG, 3) void frame_kernel(FrameP p) {
 
     // ---- per-bin work on pairs (k, 1024-k): k = lane + 64 c (c < 8), and bin 512 on lane 0
     const float* mg = p.mag + frow * NBIN;
-#pragma unroll 3
+#pragma unroll
     for (int c = 0; c < 9; ++c) {
       int k;
       if (c < 8) k = lane_b + 64 * c;
@@ -256,7 +266,8 @@ __global__ __launch_bounds__(64 * FR_PER_WG, 3) void frame_kernel(FrameP p) {
 #ifdef EXP_NOMAG
       if (KIND == K_GL_ITER || KIND == K_GL_INIT) sk = 1.f + z, sm = 2.f + z;
 #else
-      if (KIND == K_GL_ITER || KIND == K_GL_INIT) sk = mg[k], sm = mg[mkk];
+      if (KIND == K_GL_ITER) sk = c < 8 ? mk[c < 8 ? c : 0] : m512, sm = c < 8 ? mm[c < 8 ? c : 0] : m512;
+      if (KIND == K_GL_INIT) sk = mg[k], sm = mg[mkk];
 #endif
       if (KIND == K_GL_ITER) {
         const float2 uk = unit_phase(Xk), um = unit_phase(Xm);
@@ -280,7 +291,7 @@ __global__ __launch_bounds__(64 * FR_PER_WG, 3) void frame_kernel(FrameP p) {
       s[pidx(k)] = make_float2(E.x - O.y, E.y + O.x);
       if (k != 0) s[pidx(mkk)] = make_float2(E.x + O.y, -E.y + O.x);
     }
-    if (KIND == K_STFT) continue;
+    if (KIND == K_STFT) return;
 
     // ---- synthesis: inverse FFT, window, store the windowed frame
 #pragma unroll
@@ -289,7 +300,8 @@ __global__ __launch_bounds__(64 * FR_PER_WG, 3) void frame_kernel(FrameP p) {
     fft1024_tail<+1>(v, s, s_tw, lane_s, z);
     {
       const int lpe = q.lpad & ~1;
-      float* dst = p.yw_out + frow * WP;
+      // (all lanes have read their last pass from `s` before the first of these stores issues)
+      float* dst = TO_LDS ? reinterpret_cast<float*>(s) : p.yw_out + frow * WP;
       const float scale = 1.0f / MC;
 #pragma unroll
       for (int c = 0; c < 4; ++c)
@@ -310,6 +322,143 @@ __global__ __launch_bounds__(64 * FR_PER_WG, 3) void frame_kernel(FrameP p) {
   }
 }
 
+// Frames strided over the grid, windowed synthesis frames to HBM (stand-alone STFT / ISTFT).
+template <int KIND>
+__global__ __launch_bounds__(64 * FR_PER_WG, 3) void frame_kernel(FrameP p) {
+  __shared__ float2 s_tw[1024];   // W_1024^m
+  __shared__ float2 s_tw2[516];   // W_2048^k, k <= 512 (real-transform post/pre-processing)
+  __shared__ float2 s_data[FR_PER_WG][LDS_PER_FR];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  load_tables(s_tw, s_tw2, p.tw, tid);
+  __syncthreads();
+  const long total = (long)p.B * p.F;
+  for (long fi = (long)blockIdx.x * FR_PER_WG + wave; fi < total; fi += (long)gridDim.x * FR_PER_WG) {
+    const int b = (int)(fi / p.F), i = (int)(fi % p.F);
+    const int Fb = p.n_frames ? p.n_frames[b] : p.F;
+    if (i >= Fb) continue;  // wave-uniform
+    frame_body<KIND, false>(p, b, i, s_data[wave], s_tw, s_tw2, lane);
+  }
+}
+
+// One Griffin-Lim iteration (or the initial synthesis from the given phase) with the overlap-add
+// fused in.  Workgroup (x, b) owns rounds x*C .. x*C+C-1 of utterance b; round j holds frames
+// 4j .. 4j+3 (one per wave).  In sample positions a = padded index - lpad, frame i covers
+// [i*hop, i*hop + win).  After round j every position below (4j+4)*hop has received all its
+// frames: those 4*hop positions are normalised and written, the next win-hop positions become the
+// carry.  Sums run in increasing frame order from zero, as the reference's frame-by-frame
+// accumulation does.  The run is preceded by `n_halo` rounds that only rebuild the carry.
+// PADDED = 1: out[b][g] over the centre-padded signal (what the next iteration reads; the zero
+// pad of 'constant' mode is written too); PADDED = 0: out[b][m] = trimmed signal.
+struct FusedP {
+  FrameP f;
+  float* out;
+  int C, n_halo, n_rounds;  // rounds per workgroup, halo rounds, rounds per utterance
+  int carry_len;            // win - hop
+};
+
+template <int KIND, int PADDED>
+__global__ __launch_bounds__(64 * FR_PER_WG, 3) void gl_fused_kernel(FusedP P) {
+  __shared__ float2 s_tw[1024];
+  __shared__ float2 s_tw2[516];
+  __shared__ float2 s_data[FR_PER_WG][LDS_PER_FR];
+  extern __shared__ float s_carry[];  // [2][carry_len]
+  const FrameP& p = P.f;
+  const FrameGeom q = p.q;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int b = blockIdx.y;
+  const int Fb = p.n_frames ? p.n_frames[b] : p.F;
+  const int L = q.hop * (Fb - 1), Lmax = q.hop * (p.F - 1);
+  const int shift = q.lpad - (q.lpad & ~1);
+  const int K = (q.win + q.hop - 1) / q.hop;
+  load_tables(s_tw, s_tw2, p.tw, tid);
+  for (int t = tid; t < 2 * P.carry_len; t += 64 * FR_PER_WG) s_carry[t] = 0.f;
+  const int j_first = blockIdx.x * P.C, j_end = min(j_first + P.C, P.n_rounds);
+  // A thread's output positions t = tid + 256 u sit at the same offset inside a hop in every round
+  // (a round starts on a hop boundary), so the window sum-square of a fully overlapped position
+  // is computed once per thread.
+  constexpr int WSS_U = 5;
+  float wss_full[WSS_U];
+#pragma unroll
+  for (int u = 0; u < WSS_U; ++u) {
+    const int rho = (tid + 64 * FR_PER_WG * u) % q.hop;
+    float acc = 0.f;
+#pragma unroll
+    for (int kk = OLA_MAXK - 1; kk >= 0; --kk) {
+      const int n = kk * q.hop + rho;
+      if (kk < K && n < q.win) {
+        const float w = p.winpad[q.lpad + n];
+        acc += w * w;
+      }
+    }
+    wss_full[u] = acc;
+  }
+  int cur = 0;
+  for (int j = j_first - P.n_halo; j < j_end; ++j) {
+    if (j < 0) continue;  // uniform: nothing before the first frame
+    __syncthreads();      // tables / carry ready; the previous round's combine has read the frames
+    const int i = FR_PER_WG * j + wave;
+    if (i < Fb) frame_body<KIND, true>(p, b, i, s_data[wave], s_tw, s_tw2, lane);
+    __syncthreads();
+    // ---- combine: positions t = a - 4j*hop in [0, 4*hop + carry_len)
+    const float* c_old = s_carry + cur * P.carry_len;
+    float* c_new = s_carry + (cur ^ 1) * P.carry_len;
+    const int n_out = FR_PER_WG * q.hop;
+    const bool emit = j >= j_first;
+#pragma unroll 1
+    for (int u = emit ? 0 : n_out / (64 * FR_PER_WG); u * 64 * FR_PER_WG + tid < n_out + P.carry_len; ++u) {
+      const int t = u * 64 * FR_PER_WG + tid;
+      if (!emit && t < n_out) continue;
+      float acc = t < P.carry_len ? c_old[t] : 0.f;
+#pragma unroll
+      for (int w = 0; w < FR_PER_WG; ++w) {
+        const int n = t - w * q.hop;
+        if (n >= 0 && n < q.win && FR_PER_WG * j + w < Fb) acc += reinterpret_cast<const float*>(s_data[w])[n + shift];
+      }
+      if (t >= n_out) {
+        c_new[t - n_out] = acc;
+        continue;
+      }
+      const int a = FR_PER_WG * j * q.hop + t;
+      const int g = q.lpad + a, m = g - NFFT / 2;
+      float y = 0.f;
+      if (m >= 0 && m < L) {
+        // window sum-square over the frames that exist at this position
+        const int sl = FR_PER_WG * j + t / q.hop;
+        float wss = 0.f;
+        if (u < WSS_U && sl >= K - 1 && sl < Fb) {
+          // (a select chain, not an index: keeps the table in registers)
+          wss = u == 0 ? wss_full[0] : u == 1 ? wss_full[1] : u == 2 ? wss_full[2] : u == 3 ? wss_full[3] : wss_full[4];
+        } else {
+          const int rho = t % q.hop;
+#pragma unroll
+          for (int kk = OLA_MAXK - 1; kk >= 0; --kk) {
+            const int fi = sl - kk, n = kk * q.hop + rho;
+            if (kk < K && fi >= 0 && fi < Fb && n < q.win) {
+              const float w = p.winpad[q.lpad + n];
+              wss += w * w;
+            }
+          }
+        }
+        y = wss > 1.17549435e-38f ? acc / wss : acc;
+      }
+      if (PADDED) {
+        if (g < q.LP) P.out[(size_t)b * q.LP + g] = y;
+      } else {
+        if (m >= 0 && m < Lmax) P.out[(size_t)b * Lmax + m] = y;
+      }
+    }
+    cur ^= 1;
+  }
+  if (PADDED) {
+    // the first lpad samples and the tail beyond the last round belong to nobody's slot
+    if (blockIdx.x == 0)
+      for (int g = tid; g < q.lpad; g += 64 * FR_PER_WG) P.out[(size_t)b * q.LP + g] = 0.f;
+    if (j_end == P.n_rounds)
+      for (int g = q.lpad + P.n_rounds * FR_PER_WG * q.hop + tid; g < q.LP; g += 64 * FR_PER_WG)
+        P.out[(size_t)b * q.LP + g] = 0.f;
+  }
+}
+
 // Overlap-add of the windowed frames, window-sum-square normalisation (where it exceeds float32
 // tiny) and the zero part of the centre padding.  One workgroup per hop-sized slot s: padded
 // indices g = lpad + s*hop + rho, rho < hop, receive frame s-k at in-window position k*hop + rho
@@ -317,7 +466,7 @@ __global__ __launch_bounds__(64 * FR_PER_WG, 3) void frame_kernel(FrameP p) {
 // frame-by-frame accumulation does.  No divisions, every access coalesced.
 // PADDED = 1: out[b][g] over the centre-padded signal (what the next STFT reads), zeros in the pad;
 // PADDED = 0: out[b][m] = trimmed signal (m = g - n_fft/2), zero beyond the utterance's own length.
-constexpr int OLA_MAXK = 8, OLA_SLOTS = 8;
+constexpr int OLA_SLOTS = 8;
 template <int PADDED>
 __global__ __launch_bounds__(320) void ola_kernel(float* __restrict__ out, const float* __restrict__ yw,
                                                   const float* __restrict__ winpad,
@@ -517,6 +666,8 @@ int check_stft_params(const ttsx_stft_params* sp, int B, int F) {
   TTSX_ARG(sp->n_fft == NFFT, "n_fft=%d unsupported (only %d)", sp->n_fft, NFFT);
   TTSX_ARG(sp->win_length >= 2 && sp->win_length <= WP - 2, "win_length=%d outside 2..%d", sp->win_length, WP - 2);
   TTSX_ARG(sp->hop_length >= 1 && sp->hop_length <= sp->win_length, "hop_length=%d", sp->hop_length);
+  TTSX_ARG(ceil_div(sp->win_length, sp->hop_length) <= OLA_MAXK, "hop_length=%d: more than %d frames overlap",
+           sp->hop_length, OLA_MAXK);
   TTSX_ARG(sp->pad_mode == TTSX_PAD_CONSTANT || sp->pad_mode == TTSX_PAD_REFLECT, "pad_mode=%d", sp->pad_mode);
   TTSX_ARG(B >= 1 && F >= 2, "bad shape B=%d F=%d (need at least 2 frames)", B, F);
   return TTSX_OK;
@@ -532,7 +683,7 @@ FrameGeom make_geom(const ttsx_stft_params* sp, int F) {
 // scratch shared by every call in the process: windowed frames and the padded signal
 struct Scratch {
   float* yw;
-  float* ypad;
+  float* ypad;   // two padded signals back to back (an iteration reads one and writes the other)
   size_t cap_yw, cap_ypad;
 };
 Scratch g_scr = {nullptr, nullptr, 0, 0};
@@ -583,34 +734,51 @@ extern "C" int ttsx_griffin_lim(const float* mag, const float* init_phase, const
   std::lock_guard<std::mutex> lock(g_scr_mu);
   const FrameGeom q = make_geom(sp, F);
   const size_t Lmax = (size_t)sp->hop_length * (F - 1);
-  rc = ensure_scratch((size_t)B * F * WP, (size_t)B * q.LP);
+  const size_t n_pad = (size_t)B * q.LP;
+  rc = ensure_scratch(0, 2 * n_pad);
   if (rc) return rc;
-  FrameP p{};
-  p.mag = mag, p.phase01 = init_phase, p.n_frames = n_frames, p.tw = tw, p.winpad = winpad, p.B = B, p.F = F;
-  p.q = q, p.yw_out = g_scr.yw, p.ypad = g_scr.ypad;
-  const unsigned grid = frame_grid((long)B * F);
-  // slots that can hold signal samples: padded indices lpad .. n_fft/2 + Lmax
+  float* ybuf[2] = {g_scr.ypad, g_scr.ypad + n_pad};
+  FusedP P{};
+  P.f.mag = mag, P.f.phase01 = init_phase, P.f.n_frames = n_frames, P.f.tw = tw, P.f.winpad = winpad;
+  P.f.B = B, P.f.F = F, P.f.q = q;
+  // slots that can hold signal samples: padded indices lpad .. n_fft/2 + Lmax; a round = 4 slots
   const int n_slots = ceil_div(NFFT / 2 + (int)Lmax - q.lpad, q.hop);
-  const dim3 ola_grid(ceil_div(n_slots, OLA_SLOTS), B), refl_grid(NFFT / 256, B);
+  P.n_rounds = ceil_div(n_slots, FR_PER_WG);
+  P.n_halo = ceil_div(ceil_div(q.win, q.hop) - 1, FR_PER_WG);
+  P.carry_len = q.win - q.hop;
+  // rounds per workgroup: long runs amortise the halo, short ones fill the chip (3 workgroups per CU)
+  // (as many workgroups as fit on the chip at once, so that no second, mostly empty wave of them runs)
+  P.C = std::max(1, ceil_div(P.n_rounds, std::max(1, 256 * 3 / B)));
+  const dim3 grid(ceil_div(P.n_rounds, P.C), B), refl_grid(NFFT / 256, B);
+  const size_t smem = 2 * (size_t)std::max(P.carry_len, 1) * sizeof(float);
   const bool reflect = sp->pad_mode == TTSX_PAD_REFLECT;
-  frame_kernel<K_GL_INIT><<<grid, 64 * FR_PER_WG, 0, st>>>(p);
+  const bool direct = preemph == 0.f;  // without de-emphasis the last launch writes the trimmed signal itself
+  int cur = 0;
+  P.out = (direct && iters == 0) ? wav : ybuf[cur];
+  if (direct && iters == 0) gl_fused_kernel<K_GL_INIT, 0><<<grid, 64 * FR_PER_WG, smem, st>>>(P);
+  else gl_fused_kernel<K_GL_INIT, 1><<<grid, 64 * FR_PER_WG, smem, st>>>(P);
   TTSX_LAUNCH_CHECK();
   for (int it = 0; it < iters; ++it) {
-    ola_kernel<1><<<ola_grid, 320, 0, st>>>(g_scr.ypad, g_scr.yw, winpad, n_frames, B, F, q, n_slots);
-    if (reflect) reflect_pad_kernel<<<refl_grid, 256, 0, st>>>(g_scr.ypad, n_frames, B, F, q);
-    frame_kernel<K_GL_ITER><<<grid, 64 * FR_PER_WG, 0, st>>>(p);
+    if (reflect) reflect_pad_kernel<<<refl_grid, 256, 0, st>>>(ybuf[cur], n_frames, B, F, q);
+    P.f.ypad = ybuf[cur];
+    const bool last = it + 1 == iters;
+    if (last && direct) {
+      P.out = wav;
+      gl_fused_kernel<K_GL_ITER, 0><<<grid, 64 * FR_PER_WG, smem, st>>>(P);
+    } else {
+      P.out = ybuf[cur ^ 1];
+      gl_fused_kernel<K_GL_ITER, 1><<<grid, 64 * FR_PER_WG, smem, st>>>(P);
+    }
+    TTSX_LAUNCH_CHECK();
+    cur ^= 1;
+  }
+  if (!direct) {
+    // the IIR reads the trimmed part of the last padded signal
+    const int nseg = (int)((Lmax + DE_SEG - 1) / DE_SEG);
+    deemph_kernel<<<dim3(ceil_div(nseg, 64), B), 64, 0, st>>>(wav, ybuf[cur] + NFFT / 2, (size_t)q.LP, n_frames, B, F,
+                                                            sp->hop_length, preemph);
     TTSX_LAUNCH_CHECK();
   }
-  if (preemph != 0.f) {
-    // final overlap-add into the padded buffer, then the IIR reads the trimmed part of it
-    ola_kernel<1><<<ola_grid, 320, 0, st>>>(g_scr.ypad, g_scr.yw, winpad, n_frames, B, F, q, n_slots);
-    const int nseg = (int)((Lmax + DE_SEG - 1) / DE_SEG);
-    deemph_kernel<<<dim3(ceil_div(nseg, 64), B), 64, 0, st>>>(wav, g_scr.ypad + NFFT / 2, (size_t)q.LP, n_frames, B, F,
-                                                            sp->hop_length, preemph);
-  } else {
-    ola_kernel<0><<<ola_grid, 320, 0, st>>>(wav, g_scr.yw, winpad, n_frames, B, F, q, n_slots);
-  }
-  TTSX_LAUNCH_CHECK();
   // the scratch is shared by every call in the process: finish before releasing the lock
   TTSX_HIP(hipStreamSynchronize(st));
   return TTSX_OK;
