@@ -272,24 +272,31 @@ __device__ __forceinline__ const float* seg_ptr(const Seg& sg, int parity) {
   return second ? b : a;
 }
 
-// fp32 MFMA engine: one row block x NT column tiles of 16 utterances per workgroup, the K axis
+// fp32 MFMA engine: R row blocks x NT column tiles of 16 utterances per workgroup, the K axis
 // split over the 8 waves (wave w takes k-groups w, w+8, ...), partial tiles combined through LDS.
 // KGW = k-groups per wave.  The k-loop is fully unrolled and software-pipelined: the loads of
 // k-group i+D are issued before the MFMAs of k-group i, so D groups (weights from HBM, activations
 // from L2) are always in flight per wave.  (Issuing the whole weight stream first is slower here:
 // vector loads return in order, so the first activation tile would queue behind all the weights
-// and no MFMA could overlap the stream.)
-template <int NT, int KGW, int MODE>
+// and no MFMA could overlap the stream.)  The activation tiles are what bounds the big launches
+// (every workgroup re-reads its 16*NT columns of the whole K range through the vector cache; the
+// weight stream costs next to nothing beside it), hence R = 2 for the LSTMs: one activation load
+// feeds two row blocks.
+template <int R, int NT, int KGW, int MODE>
 struct GemmOp {
   typedef GemmP P;
   static __device__ __forceinline__ void run(const GemmP& p, int wg) {
     const int done = p.ctx->all_done;
-    const int rb = p.rb0 + wg % p.nrb, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int b0 = (wg / p.nrb) * (NT * 16);
-    constexpr int D = KGW < (NT == 1 ? 8 : 6) ? KGW : (NT == 1 ? 8 : 6);
-    __shared__ f32x4 red[GEMM_WAVES][NT][64];
+    const int ngrp = p.nrb / R;  // row-block groups of this launch
+    const int rb = p.rb0 + (wg % ngrp) * R, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b0 = (wg / ngrp) * (NT * 16);
+    constexpr int DMAX = (R * NT >= 4) ? 4 : (NT == 1 && R == 1 ? 8 : 6);
+    constexpr int D = KGW < DMAX ? KGW : DMAX;
+    constexpr int TILES = R * NT, TPW = (TILES + GEMM_WAVES - 1) / GEMM_WAVES;
+    __shared__ f32x4 red[GEMM_WAVES][TILES][64];
 
     const float4* W = reinterpret_cast<const float4*>(p.Wp) + ((size_t)rb * p.kg_stride + p.kg0 + wave) * 64 + lane;
+    const size_t wrs = (size_t)p.kg_stride * 64;  // float4 stride between row blocks
     // activation pointers of the (up to three) segments, positioned at this lane's quad row / column
     const size_t xoff = (size_t)(lane >> 4) * p.Bpad + b0 + (lane & 15);
     const float4* X0 = reinterpret_cast<const float4*>(seg_ptr(p.seg[0], p.parity)) + xoff;
@@ -300,57 +307,65 @@ struct GemmOp {
     auto xptr = [&](int g) -> const float4* {
       return g < e0 ? X0 + (size_t)g * xs : (g < e1 ? X1 + (size_t)(g - e0) * xs : X2 + (size_t)(g - e1) * xs);
     };
-    float4 wv[D], xv[D][NT];
+    float4 wv[D][R], xv[D][NT];
 #pragma unroll
     for (int i = 0; i < D; ++i) {
-      wv[i] = W[(size_t)i * GEMM_WAVES * 64];
+#pragma unroll
+      for (int r = 0; r < R; ++r) wv[i][r] = W[(size_t)i * GEMM_WAVES * 64 + r * wrs];
       const float4* xp = xptr(wave + i * GEMM_WAVES);
 #pragma unroll
       for (int n = 0; n < NT; ++n) xv[i][n] = xp[n * 16];
     }
-    // epilogue operands of the n-tile(s) this wave finishes
-    const int quad = rb * 4 + (lane >> 4);
-    Pre pre[(NT + GEMM_WAVES - 1) / GEMM_WAVES];
+    // epilogue operands of the tile(s) this wave finishes: tile t = r * NT + n
+    Pre pre[TPW];
 #pragma unroll
-    for (int k = 0; k < (NT + GEMM_WAVES - 1) / GEMM_WAVES; ++k) {
-      const int n = wave + k * GEMM_WAVES;
-      if (n < NT) pre[k] = prefetch_quad<MODE>(p, quad, b0 + n * 16 + (lane & 15));
+    for (int k = 0; k < TPW; ++k) {
+      const int t = wave + k * GEMM_WAVES;
+      if (t < TILES)
+        pre[k] = prefetch_quad<MODE>(p, (rb + t / NT) * 4 + (lane >> 4), b0 + (t % NT) * 16 + (lane & 15));
     }
 
-    f32x4 acc[NT];
+    f32x4 acc[R][NT];
 #pragma unroll
-    for (int n = 0; n < NT; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[r][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < KGW; ++i) {
       const int sl = i % D;
 #pragma unroll
-      for (int n = 0; n < NT; ++n) {
-        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[sl].x, xv[sl][n].x, acc[n], 0, 0, 0);
-        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[sl].y, xv[sl][n].y, acc[n], 0, 0, 0);
-        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[sl].z, xv[sl][n].z, acc[n], 0, 0, 0);
-        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[sl].w, xv[sl][n].w, acc[n], 0, 0, 0);
-      }
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[sl][r].x, xv[sl][n].x, acc[r][n], 0, 0, 0);
+          acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[sl][r].y, xv[sl][n].y, acc[r][n], 0, 0, 0);
+          acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[sl][r].z, xv[sl][n].z, acc[r][n], 0, 0, 0);
+          acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[sl][r].w, xv[sl][n].w, acc[r][n], 0, 0, 0);
+        }
       if (i + D < KGW) {
-        wv[sl] = W[(size_t)(i + D) * GEMM_WAVES * 64];
+#pragma unroll
+        for (int r = 0; r < R; ++r) wv[sl][r] = W[(size_t)(i + D) * GEMM_WAVES * 64 + r * wrs];
         const float4* xp = xptr(wave + (i + D) * GEMM_WAVES);
 #pragma unroll
         for (int n = 0; n < NT; ++n) xv[sl][n] = xp[n * 16];
       }
     }
 #pragma unroll
-    for (int n = 0; n < NT; ++n) red[wave][n][lane] = acc[n];
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) red[wave][r * NT + n][lane] = acc[r][n];
     __syncthreads();
     if (done) return;
 
-    // wave w finishes n-tile w: lane l holds rows 4*(l>>4)+{0..3} of column l&15
+    // wave w finishes tile w: lane l holds rows 4*(l>>4)+{0..3} of column l&15
 #pragma unroll
-    for (int k = 0; k < (NT + GEMM_WAVES - 1) / GEMM_WAVES; ++k) {
-      const int n = wave + k * GEMM_WAVES;
-      if (n >= NT) break;
-      f32x4 v = red[0][n][lane];
+    for (int k = 0; k < TPW; ++k) {
+      const int t = wave + k * GEMM_WAVES;
+      if (t >= TILES) break;
+      f32x4 v = red[0][t][lane];
 #pragma unroll
-      for (int w = 1; w < GEMM_WAVES; ++w) v += red[w][n][lane];
-      epilogue_quad<MODE>(p, quad, b0 + n * 16 + (lane & 15), v, pre[k]);
+      for (int w = 1; w < GEMM_WAVES; ++w) v += red[w][t][lane];
+      epilogue_quad<MODE>(p, (rb + t / NT) * 4 + (lane >> 4), b0 + (t % NT) * 16 + (lane & 15), v, pre[k]);
     }
   }
 };
@@ -809,7 +824,9 @@ void free_workspace(ttsx_t2_decoder* d) {
 int proj_rows(const ttsx_t2_decoder* d) { return d->odim + 16 + PRENET_DIM; }
 
 int ensure_workspace(ttsx_t2_decoder* d, int B, int T) {
-  const int Bpad = B <= GEMV_MAX_B ? B : (B <= 64 ? round_up(B, 16) : round_up(B, 64));
+  // column padding: 16 / 32 / multiples of 64 (a count of 3 column tiles would leave the LSTM launches
+  // with one and a half waves of workgroups: slower than padding to 64)
+  const int Bpad = B <= GEMV_MAX_B ? B : (B <= 32 ? round_up(B, 16) : round_up(B, 64));
   if (d->cap_B == Bpad && d->cap_T >= T) {
     d->Bpad = Bpad;
     return TTSX_OK;
@@ -886,49 +903,50 @@ struct Partial {
   }
 };
 
-int n_col_tiles(const ttsx_t2_decoder* d, bool split_n, int* nt) {
-  // column tiles per workgroup: 2 for the big (weight-streaming) GEMMs when the batch allows,
-  // 1 for the small ones, which need the extra workgroups more than the weight reuse
-  const int nt_total = d->Bpad / 16;
-  *nt = (!split_n && nt_total % 2 == 0) ? 2 : 1;
-  return nt_total / *nt;
-}
-
-// Launch op A (params pa, na workgroups, extra dynamic LDS `smem`) together with a partial piece.
-// PK = k-groups per wave of the partial piece (12: attention LSTM, 16: decoder LSTM).
+// Launch op A (params pa, na workgroups, extra dynamic LDS `smem`) together with a partial piece
+// (GEMV regime only).  PK = k-groups per wave of the partial piece (12: attention LSTM, 16: decoder LSTM).
 template <class A, int PK>
 int launch_with_piece(const ttsx_t2_decoder* d, const typename A::P& pa, int na, size_t smem, const Piece* pc,
                       hipStream_t st) {
   if (!pc || !pc->on) {
     dual_kernel<A, NoOp><<<na, GEMM_THREADS, smem, st>>>(pa, 0, na);
-  } else if (d->B <= GEMV_MAX_B) {
+  } else {
     const int nb = pc->g.nrb;
     if (d->B == 1) dual_kernel<A, GemvOp<1, PK, MODE_PARTIAL>><<<na + nb, GEMM_THREADS, smem, st>>>(pa, pc->g, na);
     else dual_kernel<A, GemvOp<2, PK, MODE_PARTIAL>><<<na + nb, GEMM_THREADS, smem, st>>>(pa, pc->g, na);
-  } else {
-    int nt;
-    const int tiles = n_col_tiles(d, false, &nt);
-    const int nb = pc->g.nrb * tiles;
-    if (nt == 2) dual_kernel<A, GemmOp<2, PK, MODE_PARTIAL>><<<na + nb, GEMM_THREADS, smem, st>>>(pa, pc->g, na);
-    else dual_kernel<A, GemmOp<1, PK, MODE_PARTIAL>><<<na + nb, GEMM_THREADS, smem, st>>>(pa, pc->g, na);
   }
   TTSX_LAUNCH_CHECK();
   return TTSX_OK;
 }
 
 // A GEMM/GEMV launch on the serial path (`g` covers all `nrb` row blocks) with an optional piece.
-// KGW = k-groups per wave of the main op.
+// KGW = k-groups per wave of the main op; `big`: a weight-streaming launch (LSTM) as opposed to one
+// of the small ones, which need many workgroups more than they need reuse.
 template <int MODE, int KGW, int PK>
-int launch_gemm(const ttsx_t2_decoder* d, GemmP g, int nrb, bool split_n, const Piece* pc, hipStream_t st) {
+int launch_gemm(const ttsx_t2_decoder* d, GemmP g, int nrb, bool big, const Piece* pc, hipStream_t st) {
   g.rb0 = 0, g.nrb = nrb;
   if (d->B <= GEMV_MAX_B) {
     if (d->B == 1) return launch_with_piece<GemvOp<1, KGW, MODE>, PK>(d, g, nrb, 0, pc, st);
     return launch_with_piece<GemvOp<2, KGW, MODE>, PK>(d, g, nrb, 0, pc, st);
   }
-  int nt;
-  const int tiles = n_col_tiles(d, split_n, &nt);
-  if (nt == 2) return launch_with_piece<GemmOp<2, KGW, MODE>, PK>(d, g, nrb * tiles, 0, pc, st);
-  return launch_with_piece<GemmOp<1, KGW, MODE>, PK>(d, g, nrb * tiles, 0, pc, st);
+  const int nt_total = d->Bpad / 16;
+  if (!big) return launch_with_piece<GemmOp<1, 1, KGW, MODE>, PK>(d, g, nrb * nt_total, 0, nullptr, st);
+  // Tile of a weight-streaming launch: R row blocks x NT column tiles per workgroup, code 10 R + NT.
+  // Bigger tiles re-read fewer activations, but the launch must still cover the chip: take the
+  // biggest tile that leaves at least one workgroup per CU (measured at batch 16..128).
+  int shape = 11;
+  const int cus = 256;
+  if (nrb % 2 == 0 && nrb / 2 * nt_total >= cus) shape = 21;
+  if (nrb % 2 == 0 && nt_total % 2 == 0 && nrb / 2 * (nt_total / 2) >= cus) shape = 22;
+  if (nrb % 4 == 0 && nt_total % 2 == 0 && nrb / 4 * (nt_total / 2) >= cus) shape = 42;
+  if (const char* e = getenv("TTSX_GEMM_SHAPE")) shape = atoi(e);  // tuning override
+  switch (shape) {
+    case 21: return launch_with_piece<GemmOp<2, 1, KGW, MODE>, PK>(d, g, nrb / 2 * nt_total, 0, nullptr, st);
+    case 22: return launch_with_piece<GemmOp<2, 2, KGW, MODE>, PK>(d, g, nrb / 2 * (nt_total / 2), 0, nullptr, st);
+    case 42: return launch_with_piece<GemmOp<4, 2, KGW, MODE>, PK>(d, g, nrb / 4 * (nt_total / 2), 0, nullptr, st);
+    case 24: return launch_with_piece<GemmOp<2, 4, KGW, MODE>, PK>(d, g, nrb / 2 * (nt_total / 4), 0, nullptr, st);
+    default: return launch_with_piece<GemmOp<1, 1, KGW, MODE>, PK>(d, g, nrb * nt_total, 0, nullptr, st);
+  }
 }
 
 constexpr int KG1 = (PRENET_DIM + ENC_DIM + QUERY_DIM) / 16, KG2 = (ENC_DIM + QUERY_DIM + DEC_DIM) / 16;
@@ -948,9 +966,7 @@ hipError_t set_context_lds(size_t bytes) {
   hipError_t e;
   if ((e = set_context_lds_for<NoOp>(bytes)) != hipSuccess) return e;
   if ((e = set_context_lds_for<GemvOp<1, PK2, MODE_PARTIAL>>(bytes)) != hipSuccess) return e;
-  if ((e = set_context_lds_for<GemvOp<2, PK2, MODE_PARTIAL>>(bytes)) != hipSuccess) return e;
-  if ((e = set_context_lds_for<GemmOp<1, PK2, MODE_PARTIAL>>(bytes)) != hipSuccess) return e;
-  return set_context_lds_for<GemmOp<2, PK2, MODE_PARTIAL>>(bytes);
+  return set_context_lds_for<GemvOp<2, PK2, MODE_PARTIAL>>(bytes);
 }
 
 // Early columns of the attention LSTM, [ctx(t-1); h_a(t-1)] -> g_a, for the step with chunk index i.
@@ -1000,7 +1016,7 @@ int enqueue_step(ttsx_t2_decoder* d, int i, bool first, bool more, hipStream_t s
   g.out[0] = d->x2, g.relu = 1;
   pc = pa.piece(2);
   pc.on = split && !first;
-  if ((rc = launch_gemm<MODE_LINEAR, 2, PK1>(d, g, PRENET_DIM / 16, true, &pc, st))) return rc;
+  if ((rc = launch_gemm<MODE_LINEAR, 2, PK1>(d, g, PRENET_DIM / 16, false, &pc, st))) return rc;
   // attention LSTM: [x2; ctx; h_a] (split: late columns [x2] + the partial sums) + cell update
   g.Wp = d->w_lstm1, g.bias = d->b_lstm1, g.kg0 = 0, g.kg_stride = KG1;
   g.seg[0] = Seg{{d->x2, nullptr}, 0, PRENET_DIM / 16};
@@ -1009,10 +1025,10 @@ int enqueue_step(ttsx_t2_decoder* d, int i, bool first, bool more, hipStream_t s
   g.out[0] = d->h_a[0], g.out[1] = d->h_a[1], g.c = d->c_a, g.relu = 0;
   if (split) {
     g.nseg = 1, g.KG = PRENET_DIM / 16, g.gates = d->g_a;
-    rc = launch_gemm<MODE_LSTM, 2, PK1>(d, g, QUERY_DIM / 4, false, nullptr, st);
+    rc = launch_gemm<MODE_LSTM, 2, PK1>(d, g, QUERY_DIM / 4, true, nullptr, st);
   } else {
     g.nseg = 3, g.KG = KG1, g.gates = nullptr;
-    rc = launch_gemm<MODE_LSTM, KG1 / GEMM_WAVES, PK1>(d, g, QUERY_DIM / 4, false, nullptr, st);
+    rc = launch_gemm<MODE_LSTM, KG1 / GEMM_WAVES, PK1>(d, g, QUERY_DIM / 4, true, nullptr, st);
   }
   if (rc) return rc;
   // query projection   (+ first third of the decoder partial)
@@ -1022,7 +1038,7 @@ int enqueue_step(ttsx_t2_decoder* d, int i, bool first, bool more, hipStream_t s
   g.out[0] = d->q, g.out[1] = nullptr, g.c = nullptr;
   pc = pd.piece(0);
   pc.on = split;
-  if ((rc = launch_gemm<MODE_LINEAR, 8, PK2>(d, g, ATT_DIM / 16, true, &pc, st))) return rc;
+  if ((rc = launch_gemm<MODE_LINEAR, 8, PK2>(d, g, ATT_DIM / 16, false, &pc, st))) return rc;
   // attention   (+ second and last third of the decoder partial)
   AttnP ap{};
   ap.q = d->q, ap.P = d->P;
@@ -1055,10 +1071,10 @@ int enqueue_step(ttsx_t2_decoder* d, int i, bool first, bool more, hipStream_t s
   pc.on = split && more;
   if (split) {
     g.nseg = 1, g.KG = ENC_DIM / 16, g.gates = d->g_d;
-    rc = launch_gemm<MODE_LSTM, 4, PK1>(d, g, DEC_DIM / 4, false, &pc, st);
+    rc = launch_gemm<MODE_LSTM, 4, PK1>(d, g, DEC_DIM / 4, true, &pc, st);
   } else {
     g.nseg = 3, g.KG = KG2, g.gates = nullptr;
-    rc = launch_gemm<MODE_LSTM, KG2 / GEMM_WAVES, PK1>(d, g, DEC_DIM / 4, false, nullptr, st);
+    rc = launch_gemm<MODE_LSTM, KG2 / GEMM_WAVES, PK1>(d, g, DEC_DIM / 4, true, nullptr, st);
   }
   if (rc) return rc;
   // projection: mel rows, stop row, next step's prenet layer-1 rows   (+ second third)
@@ -1069,7 +1085,7 @@ int enqueue_step(ttsx_t2_decoder* d, int i, bool first, bool more, hipStream_t s
   g.out[0] = d->o, g.out[1] = nullptr, g.c = nullptr, g.x1 = d->x1, g.o_quads = d->odim / 4;
   pc = pa_next.piece(1);
   pc.on = split && more;
-  return launch_gemm<MODE_PROJ, 12, PK1>(d, g, ceil_div(proj_rows(d), 16), true, &pc, st);
+  return launch_gemm<MODE_PROJ, 12, PK1>(d, g, ceil_div(proj_rows(d), 16), false, &pc, st);
 }
 
 int push_ctx(ttsx_t2_decoder* d, hipStream_t st) {
@@ -1207,9 +1223,10 @@ extern "C" int ttsx_t2_decoder_begin(ttsx_t2_decoder* d, const float* enc, const
   if (rc) return rc;
   d->B = B, d->T = T;
   {
-    // early/late LSTM split: pays where the launches are latency-bound (GEMV regime); TTSX_SPLIT=0/1 overrides
+    // early/late LSTM split: pays where the launches are latency-bound (GEMV regime; measured slower
+    // on the MFMA path, where the pieces cost a full activation pass each); TTSX_SPLIT=0 turns it off
     const char* e = getenv("TTSX_SPLIT");
-    d->split = e ? e[0] == '1' : B <= GEMV_MAX_B;
+    d->split = B <= GEMV_MAX_B && !(e && e[0] == '0');
   }
   d->parity0 = 0;
   const size_t cb = d->Bpad;
