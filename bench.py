@@ -174,8 +174,16 @@ def main():
     else:
         roof = dict(bound="hbm", achieved=nbytes / (dec_us * 1e-6) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
     roof["frac"] = roof["achieved"] / roof["peak"]
+    # HBM bytes per step from the PMC passes kept under profiles/ (a separate rocprofv3 run on the same
+    # workload; counters cannot be read from inside this process)
     roof["traffic"] = None
-    roof["kernel"] = "t2 decoder step (prenet_stop + 4 rowblock_gemm + attention launches)"
+    pmc_path = os.path.join(ROOT, "profiles", "r1_decoder_pmc.json")
+    if os.path.exists(pmc_path):
+        pmc = json.load(open(pmc_path))
+        if (pmc.get("B"), pmc.get("T")) == (B, T):
+            roof["traffic"] = pmc["hbm_bytes_per_step"]
+            roof["traffic_source"] = "profiles/r1_decoder_pmc.csv"
+    roof["kernel"] = "t2 decoder step (7 launches: prenet-2, attention LSTM, query, energies, context, decoder LSTM, projection)"
     roof["us_per_launch_group"] = dec_us
     roof["algorithmic_bytes"] = nbytes
     roof["algorithmic_flops"] = flops
