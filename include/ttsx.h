@@ -318,6 +318,20 @@ int ttsx_stft(const float* y, int B, int F, const ttsx_stft_params* sp, float* s
 int ttsx_istft(const float* spec_re, const float* spec_im, int B, int F, const ttsx_stft_params* sp,
                float* y, void* stream);
 
+/* ------------------------------------------------------------------ post-vocoder tail of a request
+ * Replaces the per-sentence tail of Synthesizer.tts (Tacotron2/TTS/synthesizer.py:141-174):
+ * trim_silence -> AudioProcessor.find_endpoint (Tacotron2/TTS/utils.py:944-951), concatenation with
+ * `gap` (10 000) zero samples after every sentence, and the int16 scaling of save_wav (utils.py:794-796).
+ *   wav        [B,pitch] float32 waveforms, n_samples [B] int32 valid samples per sentence or NULL (= pitch)
+ *   window_length = int(sample_rate * 0.8), hop_length = int(window_length / 4), threshold = 10^(-40/20)
+ *   do_trim    0: keep every sentence whole
+ *   endpoints  [B] int32 out, offsets [B+1] int32 out (start of every sentence in pcm; total at [B])
+ *   pcm        [capacity] int16 out, capacity >= B*(pitch+gap);  *total_host = samples written,
+ *              *peak_host = max |sample| before scaling.  Synchronises `stream`.                       */
+int ttsx_request_tail(const float* wav, const int32_t* n_samples, int B, int pitch, int window_length, int hop_length,
+                      float threshold, int gap, int do_trim, int32_t* endpoints, int32_t* offsets, int16_t* pcm,
+                      long capacity, long* total_host, float* peak_host, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -5,7 +5,7 @@ caller gets an exception.
 """
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_long, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, os.environ.get("TTSX_LIB", "libttsx.so"))
@@ -106,6 +106,8 @@ PROTOTYPES = {
                                  c_void_p]),
     "ttsx_stft": (c_int, [_fp, c_int, c_int, POINTER(StftParams), _fp, _fp, c_void_p]),
     "ttsx_istft": (c_int, [_fp, _fp, c_int, c_int, POINTER(StftParams), _fp, c_void_p]),
+    "ttsx_request_tail": (c_int, [_fp, _fp, c_int, c_int, c_int, c_int, c_float, c_int, c_int, _fp, _fp, _fp,
+                                  c_long, POINTER(c_long), POINTER(c_float), c_void_p]),
 }
 
 _lib = None

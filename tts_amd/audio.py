@@ -14,6 +14,7 @@ run can be reproduced; when omitted the phase comes from `np.random.rand`, as
 in the reference (utils.py:923).  `tacotron_v1=True` selects the Tacotron
 tree's STFT parameters (win_length from frame_length_ms, reflect padding).
 """
+import ctypes
 import io
 
 import numpy as np
@@ -197,6 +198,31 @@ class AudioProcessor(object):
                                             int(self.griffin_lim_iters), pre, _lib.ptr(wav),
                                             _lib.current_stream()), "ttsx_griffin_lim")
         return wav
+
+    def request_tail(self, wav, n_samples=None, gap=10000, trim=True, threshold_db=-40, min_silence_sec=0.8):
+        """Device-side tail of a request: wav [B,L] float32 (device) -> (pcm int16 ndarray, endpoints
+        [B] ndarray, peak).  Every sentence is cut at `find_endpoint`, followed by `gap` zeros, and
+        the concatenation is scaled as `save_wav` does (Tacotron2/TTS/synthesizer.py:166-173)."""
+        lib = _lib.load()
+        wav = wav.contiguous().float()
+        B, L = wav.shape
+        dev = wav.device
+        if n_samples is not None:
+            n_samples = torch.as_tensor(n_samples).to(device=dev, dtype=torch.int32).contiguous()
+        window = int(self.sample_rate * min_silence_sec)
+        hop = int(window / 4)
+        cap = B * (L + gap)
+        endpoints = torch.empty(B, device=dev, dtype=torch.int32)
+        offsets = torch.empty(B + 1, device=dev, dtype=torch.int32)
+        pcm = torch.empty(cap, device=dev, dtype=torch.int16)
+        total, peak = ctypes.c_long(0), ctypes.c_float(0.0)
+        with torch.cuda.device(dev):
+            _lib.check(lib.ttsx_request_tail(_lib.ptr(wav), _lib.ptr(n_samples), B, L, window, hop,
+                                             float(self._db_to_amp(threshold_db)), int(gap), 1 if trim else 0,
+                                             _lib.ptr(endpoints), _lib.ptr(offsets), _lib.ptr(pcm), cap,
+                                             ctypes.byref(total), ctypes.byref(peak), _lib.current_stream()),
+                       "ttsx_request_tail")
+        return pcm[:total.value].cpu().numpy(), endpoints.cpu().numpy(), float(peak.value)
 
     # ---- reference-shaped API (NumPy in, NumPy out) --------------------------
     def _phase(self, shape, init_phase):

@@ -83,9 +83,36 @@ class Synthesizer(object):
             inputs = text_to_seqvec(ids, self.tts_config, True)
             decoder_output, postnet_output, alignments, _ = run_model(self.model, inputs, self.tts_config, False)
             postnet_output, _, _ = parse_outputs(postnet_output, decoder_output, alignments)
-            ph = None if init_phases is None else init_phases[i]
+            ph = None if init_phases is None else np.asarray(init_phases[i])[:, :postnet_output.shape[0]]
             wav = inv_spectrogram(postnet_output, self.ap, self.tts_config, ph)
             wav = trim_silence(wav, self.ap)
             wavs += list(wav)
             wavs += [0] * 10000
         return wav_bytes(self.ap, np.asarray(wavs))
+
+    def tts_ids_batched(self, sentences_ids, init_phases=None):
+        """The same request as `tts_ids`, with all its sentences decoded as ONE padded batch
+        (per-utterance stop and length masks make every row equal to its own batch-1 run), one
+        batched Griffin-Lim, and the endpoint trim / 10 000-sample gaps / int16 scaling done on the
+        device (`ttsx_request_tail`).  Returns the WAV file as a BytesIO like `tts_ids`.  Tacotron2 only."""
+        import io
+        import scipy.io.wavfile
+        lens = [len(ids) for ids in sentences_ids]
+        ids = np.zeros((len(lens), max(lens)), dtype=np.int64)
+        for b, seq in enumerate(sentences_ids):
+            ids[b, :lens[b]] = np.asarray(seq, dtype=np.int64)
+        out = self.model.inference_batch(torch.as_tensor(ids), text_lengths=torch.as_tensor(lens))
+        post = out["postnet_output"]
+        n_frames = (out["n_steps"] * self.model.decoder.r).to(torch.int32)
+        B, Fm, _ = post.shape
+        nf = n_frames.cpu().numpy()
+        phase = torch.zeros(B, Fm, self.ap.num_freq, device=post.device)
+        for b in range(B):
+            ph = np.random.rand(self.ap.num_freq, int(nf[b])) if init_phases is None else np.asarray(init_phases[b])[:, :int(nf[b])]
+            phase[b, :nf[b]] = torch.from_numpy(np.ascontiguousarray(ph.T.astype(np.float32)))
+        wav = self.ap.griffin_lim_batch(self.ap.spec_to_mag(post), phase, n_frames)
+        n_samples = (n_frames.clamp(min=1) - 1) * self.ap.hop_length
+        pcm, self.last_endpoints, _ = self.ap.request_tail(wav, n_samples)
+        buf = io.BytesIO()
+        scipy.io.wavfile.write(buf, self.ap.sample_rate, pcm)
+        return buf
