@@ -174,6 +174,26 @@ int ttsx_encoder_convs_destroy(ttsx_encoder_convs* p);
 int ttsx_encoder_convs_run(ttsx_encoder_convs* p, const float* x, const int32_t* lengths, int B, int T, float* out,
                            void* stream);
 
+/* Encoder BiLSTM: nn.LSTM(512, 256, bidirectional, batch_first) of Encoder (Tacotron2/TTS/models.py:419-427)
+ * as run by Encoder.inference (:449-454).  Index 0 = forward (encoder.lstm.*_l0), 1 = reverse (*_l0_reverse). */
+typedef struct {
+  const float* w_ih[2]; /* encoder.lstm.weight_ih_l0[_reverse] [1024,512] (gate order i,f,g,o) */
+  const float* w_hh[2]; /* encoder.lstm.weight_hh_l0[_reverse] [1024,256] */
+  const float* b_ih[2]; /* encoder.lstm.bias_ih_l0[_reverse]   [1024] */
+  const float* b_hh[2]; /* encoder.lstm.bias_hh_l0[_reverse]   [1024] */
+} ttsx_encoder_lstm_weights;
+
+typedef struct ttsx_encoder_lstm ttsx_encoder_lstm;
+
+int ttsx_encoder_lstm_create(const ttsx_encoder_lstm_weights* w, void* stream, ttsx_encoder_lstm** out);
+int ttsx_encoder_lstm_destroy(ttsx_encoder_lstm* p);
+/*   x        [B,T,512] output of the conv blocks, position-major
+ *   lengths  [B] int32 or NULL (= T): an utterance is processed as its own unpadded sequence
+ *            (what pack_padded_sequence gives); rows at positions >= length are zero
+ *   out      [B,T,512] = [forward 256 | backward 256]                                    */
+int ttsx_encoder_lstm_run(ttsx_encoder_lstm* p, const float* x, const int32_t* lengths, int B, int T, float* out,
+                          void* stream);
+
 /* ------------------------------------------------------------------ Tacotron (v1)
  * Replaces Tacotron.forward in eval mode, Tacotron/TTS/models.py:692-700:
  *   encoder   Prenet (:250-253) + CBHG K=16 (:412-434, BatchNormConv1d :307-313, Highway :331-334)

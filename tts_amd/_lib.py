@@ -67,6 +67,10 @@ class T1Weights(Structure):
                 ("last_linear_w", _fp), ("last_linear_b", _fp)]
 
 
+class EncoderLstmWeights(Structure):
+    _fields_ = [("w_ih", _fp * 2), ("w_hh", _fp * 2), ("b_ih", _fp * 2), ("b_hh", _fp * 2)]
+
+
 class StftParams(Structure):
     _fields_ = [("n_fft", c_int), ("hop_length", c_int), ("win_length", c_int), ("pad_mode", c_int)]
 
@@ -95,6 +99,9 @@ PROTOTYPES = {
     "ttsx_encoder_convs_create": (c_int, [POINTER(EncoderConvWeights), c_void_p, POINTER(c_void_p)]),
     "ttsx_encoder_convs_destroy": (c_int, [c_void_p]),
     "ttsx_encoder_convs_run": (c_int, [c_void_p, _fp, _fp, c_int, c_int, _fp, c_void_p]),
+    "ttsx_encoder_lstm_create": (c_int, [POINTER(EncoderLstmWeights), c_void_p, POINTER(c_void_p)]),
+    "ttsx_encoder_lstm_destroy": (c_int, [c_void_p]),
+    "ttsx_encoder_lstm_run": (c_int, [c_void_p, _fp, _fp, c_int, c_int, _fp, c_void_p]),
     "ttsx_t1_create": (c_int, [POINTER(T1Weights), c_int, c_int, c_int, c_void_p, POINTER(c_void_p)]),
     "ttsx_t1_destroy": (c_int, [c_void_p]),
     "ttsx_t1_encoder_run": (c_int, [c_void_p, _fp, _fp, c_int, c_int, _fp, c_void_p]),

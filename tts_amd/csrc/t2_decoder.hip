@@ -189,6 +189,14 @@ struct GemmP {
   int rb0, nrb;        // row blocks rb0 .. rb0+nrb-1 are this launch's; workgroup id = tile * nrb + (rb - rb0)
   int parity;          // (decoder steps completed before this one) & 1: selects the h ping-pong buffers
   float* gates;        // PARTIAL: raw sums out (quad layout); LSTM: sums of the partial launch, added in
+  int gates_pitch;     // columns per quad row of `gates` (0: Bpad) and first column of this launch in it
+  int gates_col0;
+  // LSTM over a sequence (encoder): h also goes to seq_out[b * seq_pitch + unit]; columns whose
+  // utterance does not reach time index t_index (t_index >= len[b]) hold zero state and output
+  float* seq_out;
+  size_t seq_pitch;
+  const int32_t* len;
+  int t_index, n_valid;  // n_valid: utterances (columns below it are real)
   float* out[2];  // LINEAR/PROJ: out[0] quad layout; LSTM: h ping-pong pair, written at parity^1
   float* c;       // LSTM cell state, quad layout
   float* x1;      // PROJ: prenet layer-1 activations for the next step, quad layout
@@ -210,7 +218,8 @@ __device__ __forceinline__ Pre prefetch_quad(const GemmP& p, int quad, int b) {
   if (MODE != MODE_PARTIAL) r.bias = reinterpret_cast<const float4*>(p.bias)[quad];
   if (MODE == MODE_LSTM) {
     r.c = p.c[qidx(quad, b, p.Bpad)];
-    if (p.gates) r.gates = reinterpret_cast<const float4*>(p.gates)[(size_t)quad * p.Bpad + b];
+    const int gp = p.gates_pitch ? p.gates_pitch : p.Bpad;
+    if (p.gates) r.gates = reinterpret_cast<const float4*>(p.gates)[(size_t)quad * gp + p.gates_col0 + b];
   }
   return r;
 }
@@ -220,7 +229,8 @@ template <int MODE>
 __device__ __forceinline__ void epilogue_quad(const GemmP& p, int quad, int b, f32x4 v, const Pre& pre) {
   const int Bpad = p.Bpad;
   if (MODE == MODE_PARTIAL) {
-    reinterpret_cast<float4*>(p.gates)[(size_t)quad * Bpad + b] = make_float4(v[0], v[1], v[2], v[3]);
+    const int gp = p.gates_pitch ? p.gates_pitch : Bpad;
+    reinterpret_cast<float4*>(p.gates)[(size_t)quad * gp + p.gates_col0 + b] = make_float4(v[0], v[1], v[2], v[3]);
     return;
   }
   v[0] += pre.bias.x, v[1] += pre.bias.y, v[2] += pre.bias.z, v[3] += pre.bias.w;
@@ -228,8 +238,13 @@ __device__ __forceinline__ void epilogue_quad(const GemmP& p, int quad, int b, f
     // the four rows are gates i,f,g,o of hidden unit `quad`
     const size_t idx = qidx(quad, b, Bpad);
     v[0] += pre.gates.x, v[1] += pre.gates.y, v[2] += pre.gates.z, v[3] += pre.gates.w;
-    const float c_new = sigmoidf_(v[1]) * pre.c + sigmoidf_(v[0]) * tanhf(v[2]);
-    const float h_new = sigmoidf_(v[3]) * tanhf(c_new);
+    float c_new = sigmoidf_(v[1]) * pre.c + sigmoidf_(v[0]) * tanhf(v[2]);
+    float h_new = sigmoidf_(v[3]) * tanhf(c_new);
+    if (p.seq_out) {
+      const bool live = b < p.n_valid && (!p.len || p.t_index < p.len[b]);
+      if (!live) c_new = 0.f, h_new = 0.f;
+      if (b < p.n_valid) p.seq_out[(size_t)b * p.seq_pitch + quad] = h_new;
+    }
     p.c[idx] = c_new;
     float* h_out = p.parity ? p.out[0] : p.out[1];
     h_out[idx] = h_new;
@@ -1393,5 +1408,166 @@ extern "C" int ttsx_t2_decoder_run(ttsx_t2_decoder* d, const float* enc, const i
   if (steps_run_host) *steps_run_host = run;
   d->steps_done = run;
   d->begun = false;  // the state belongs to a finished batch
+  return TTSX_OK;
+}
+
+// ====================================================================== encoder BiLSTM
+// Encoder.inference's bidirectional LSTM (Tacotron2/TTS/models.py:419-454: nn.LSTM(512, 256,
+// bidirectional, batch_first)) on the same row-block engine.
+//   * input projection of every time step at once: [1024 x 512] x [512 x T*Bc] per direction,
+//     a MODE_PARTIAL launch whose "utterance" axis is (t, b) (column t*Bc + b);
+//   * T step launches; each is a dual launch (forward direction at t = s, backward at t = T-1-s)
+//     of the K = 256 recurrent product with the cell update in the epilogue, which adds the
+//     input-projection sums of its time step and writes h to out[b][t][dir*256 + unit].
+// Utterances shorter than T hold zero state outside their length (what packing the sequence does).
+namespace {
+
+constexpr int ENC_H = 256, ENC_IN = 512;
+
+// y [B][T][512] (frame-major) -> quad layout [128][Ct] float4 with column t*Bc + b; padding columns zero
+__global__ void enc_to_quad_kernel(float4* __restrict__ xq, const float4* __restrict__ y, int B, int T, int Bc, int Ct) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)Ct * (ENC_IN / 4)) return;
+  const int k4 = (int)(i % (ENC_IN / 4)), col = (int)(i / (ENC_IN / 4));
+  const int t = col / Bc, b = col % Bc;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (t < T && b < B) v = y[((size_t)b * T + t) * (ENC_IN / 4) + k4];
+  xq[(size_t)k4 * Ct + col] = v;
+}
+
+}  // namespace
+
+struct ttsx_encoder_lstm {
+  float *w_ih[2], *b_unused[2], *w_hh[2], *bias[2];
+  RunCtx* rc;
+  // workspace
+  int cap_B, cap_T, Bc, Ct;
+  float *xq, *gi[2], *h[2][2], *c[2];
+};
+
+namespace {
+
+void enc_lstm_free_ws(ttsx_encoder_lstm* e) {
+  float** bufs[] = {&e->xq, &e->gi[0], &e->gi[1], &e->h[0][0], &e->h[0][1], &e->h[1][0], &e->h[1][1], &e->c[0], &e->c[1]};
+  for (float** b : bufs) {
+    if (*b) (void)hipFree(*b);
+    *b = nullptr;
+  }
+  e->cap_B = e->cap_T = 0;
+}
+
+// one launch of the engine with a GemmP prepared by the caller; cols = column count, step = recurrent step launch
+template <int MODE, int KGW>
+int enc_launch_one(const GemmP& g, int nrb, int Bc, int cols, hipStream_t st) {
+  const int nt_total = cols / 16;
+  if (Bc == 1 && MODE == MODE_LSTM) dual_kernel<GemvOp<1, KGW, MODE>, NoOp><<<nrb, GEMM_THREADS, 0, st>>>(g, 0, nrb);
+  else if (Bc == 2 && MODE == MODE_LSTM) dual_kernel<GemvOp<2, KGW, MODE>, NoOp><<<nrb, GEMM_THREADS, 0, st>>>(g, 0, nrb);
+  else if (nt_total % 2 == 0 && nrb / 2 * (nt_total / 2) >= 256) {
+    const int n = nrb / 2 * (nt_total / 2);
+    dual_kernel<GemmOp<2, 2, KGW, MODE>, NoOp><<<n, GEMM_THREADS, 0, st>>>(g, 0, n);
+  } else {
+    const int n = nrb * nt_total;
+    dual_kernel<GemmOp<1, 1, KGW, MODE>, NoOp><<<n, GEMM_THREADS, 0, st>>>(g, 0, n);
+  }
+  TTSX_LAUNCH_CHECK();
+  return TTSX_OK;
+}
+
+}  // namespace
+
+extern "C" int ttsx_encoder_lstm_create(const ttsx_encoder_lstm_weights* w, void* stream, ttsx_encoder_lstm** out) {
+  TTSX_ARG(w && out, "ttsx_encoder_lstm_create: null argument");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  ttsx_encoder_lstm* e = new ttsx_encoder_lstm();
+  memset(e, 0, sizeof(*e));
+  int rc = 0;
+  for (int d = 0; d < 2; ++d) {
+    TTSX_ARG(w->w_ih[d] && w->w_hh[d] && w->b_ih[d] && w->b_hh[d], "ttsx_encoder_lstm_create: null weight");
+    // input projection carries no bias (MODE_PARTIAL); both biases are added by the step launch
+    rc |= pack_layer(&e->w_ih[d], &e->b_unused[d], w->w_ih[d], ENC_IN, nullptr, 0, nullptr, nullptr, 4 * ENC_H, ENC_H, st);
+    rc |= pack_layer(&e->w_hh[d], &e->bias[d], w->w_hh[d], ENC_H, nullptr, 0, w->b_ih[d], w->b_hh[d], 4 * ENC_H, ENC_H, st);
+  }
+  if (rc) return TTSX_ERR_HIP;
+  TTSX_HIP(hipMalloc(reinterpret_cast<void**>(&e->rc), sizeof(RunCtx)));
+  TTSX_HIP(hipMemsetAsync(e->rc, 0, sizeof(RunCtx), st));
+  TTSX_HIP(hipStreamSynchronize(st));
+  *out = e;
+  return TTSX_OK;
+}
+
+extern "C" int ttsx_encoder_lstm_destroy(ttsx_encoder_lstm* e) {
+  if (!e) return TTSX_OK;
+  enc_lstm_free_ws(e);
+  for (int d = 0; d < 2; ++d) {
+    float* bufs[] = {e->w_ih[d], e->b_unused[d], e->w_hh[d], e->bias[d]};
+    for (float* b : bufs)
+      if (b) (void)hipFree(b);
+  }
+  if (e->rc) (void)hipFree(e->rc);
+  delete e;
+  return TTSX_OK;
+}
+
+extern "C" int ttsx_encoder_lstm_run(ttsx_encoder_lstm* e, const float* x, const int32_t* lengths, int B, int T,
+                                     float* out, void* stream) {
+  TTSX_ARG(e && x && out, "ttsx_encoder_lstm_run: null argument");
+  TTSX_ARG(B >= 1 && B <= 4096 && T >= 1, "ttsx_encoder_lstm_run: bad shape B=%d T=%d", B, T);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int Bc = B <= GEMV_MAX_B ? B : (B <= 32 ? round_up(B, 16) : round_up(B, 64));
+  const int Ct = round_up(T * Bc, 64);
+  if (e->cap_B != Bc || e->cap_T < T) {
+    enc_lstm_free_ws(e);
+    const size_t ct = Ct;
+    int rc = dev_alloc(&e->xq, ENC_IN * ct);
+    for (int d = 0; d < 2; ++d) {
+      rc |= dev_alloc(&e->gi[d], 4 * ENC_H * ct);
+      rc |= dev_alloc(&e->c[d], (size_t)ENC_H * Bc);
+      for (int i = 0; i < 2; ++i) rc |= dev_alloc(&e->h[d][i], (size_t)ENC_H * Bc);
+    }
+    if (rc) return TTSX_ERR_HIP;
+    e->cap_B = Bc, e->cap_T = T;
+  }
+  e->Bc = Bc, e->Ct = Ct;
+  {
+    const size_t n = (size_t)Ct * (ENC_IN / 4);
+    enc_to_quad_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(reinterpret_cast<float4*>(e->xq),
+                                                                  reinterpret_cast<const float4*>(x), B, T, Bc, Ct);
+    TTSX_LAUNCH_CHECK();
+  }
+  int rc;
+  for (int d = 0; d < 2; ++d) {
+    TTSX_HIP(hipMemsetAsync(e->h[d][0], 0, sizeof(float) * ENC_H * Bc, st));
+    TTSX_HIP(hipMemsetAsync(e->c[d], 0, sizeof(float) * ENC_H * Bc, st));
+    GemmP g{};
+    g.Wp = e->w_ih[d], g.nseg = 1, g.KG = ENC_IN / 16, g.Bpad = Ct, g.kg0 = 0, g.kg_stride = ENC_IN / 16;
+    g.rb0 = 0, g.nrb = ENC_H / 4, g.seg[0] = Seg{{e->xq, nullptr}, 0, ENC_IN / 16};
+    g.gates = e->gi[d], g.ctx = e->rc;
+    if ((rc = enc_launch_one<MODE_PARTIAL, ENC_IN / 16 / GEMM_WAVES>(g, ENC_H / 4, Bc, Ct, st))) return rc;
+  }
+  for (int s = 0; s < T; ++s) {
+    GemmP g[2];
+    for (int d = 0; d < 2; ++d) {
+      const int t = d == 0 ? s : T - 1 - s;
+      GemmP& q = g[d];
+      q = GemmP{};
+      q.Wp = e->w_hh[d], q.bias = e->bias[d], q.nseg = 1, q.KG = ENC_H / 16, q.Bpad = Bc, q.kg0 = 0;
+      q.kg_stride = ENC_H / 16, q.rb0 = 0, q.nrb = ENC_H / 4, q.parity = s & 1;
+      q.seg[0] = Seg{{e->h[d][0], e->h[d][1]}, 1, ENC_H / 16};
+      q.gates = e->gi[d], q.gates_pitch = Ct, q.gates_col0 = t * Bc;
+      q.out[0] = e->h[d][0], q.out[1] = e->h[d][1], q.c = e->c[d], q.ctx = e->rc;
+      q.seq_out = out + (size_t)t * (2 * ENC_H) + d * ENC_H, q.seq_pitch = (size_t)T * 2 * ENC_H;
+      q.len = lengths, q.t_index = t, q.n_valid = B;
+    }
+    // both directions in one launch
+    constexpr int KGW = ENC_H / 16 / GEMM_WAVES;
+    const int nrb = ENC_H / 4;
+    if (Bc == 1) dual_kernel<GemvOp<1, KGW, MODE_LSTM>, GemvOp<1, KGW, MODE_LSTM>><<<2 * nrb, GEMM_THREADS, 0, st>>>(g[0], g[1], nrb);
+    else if (Bc == 2) dual_kernel<GemvOp<2, KGW, MODE_LSTM>, GemvOp<2, KGW, MODE_LSTM>><<<2 * nrb, GEMM_THREADS, 0, st>>>(g[0], g[1], nrb);
+    else {
+      const int n = nrb * (Bc / 16);
+      dual_kernel<GemmOp<1, 1, KGW, MODE_LSTM>, GemmOp<1, 1, KGW, MODE_LSTM>><<<2 * n, GEMM_THREADS, 0, st>>>(g[0], g[1], n);
+    }
+    TTSX_LAUNCH_CHECK();
+  }
   return TTSX_OK;
 }

@@ -4,9 +4,9 @@ Mirrors `Tacotron2` of the reference (Tacotron2/TTS/models.py:727-813) for the
 serving path: constructor arguments, `load_state_dict`, `cuda`, `eval`,
 `decoder.max_decoder_steps`, `decoder.set_r`, `decoder.r` and
 `inference(text, speaker_ids=None)` with the same return tuple.  The decoder
-loop, attention, postnet run in hand-written HIP kernels through the C ABI;
-the encoder (embedding, 3 conv blocks, BiLSTM; once per utterance, <1 % of the
-time) uses stock PyTorch-ROCm ops.
+loop, attention, postnet and the encoder (3 conv blocks, BiLSTM) run in
+hand-written HIP kernels through the C ABI; only the embedding lookup is a
+stock PyTorch-ROCm op.
 
 Extensions the reference does not have (its `inference` is batch-1 only,
 models.py:661): `inference_batch` decodes B utterances at once with
@@ -74,7 +74,7 @@ class Tacotron2:
         self._dec_handle = None
         self._post_handle = None
         self._enc_handle = None
-        self._lstm = None
+        self._lstm_handle = None
 
     # ---- torch.nn.Module look-alikes ------------------------------------
     def load_state_dict(self, state_dict, strict=True):
@@ -137,6 +137,9 @@ class Tacotron2:
         if self._enc_handle is not None:
             _lib.load().ttsx_encoder_convs_destroy(self._enc_handle)
             self._enc_handle = None
+        if self._lstm_handle is not None:
+            _lib.load().ttsx_encoder_lstm_destroy(self._lstm_handle)
+            self._lstm_handle = None
 
     def _upload(self):
         lib = _lib.load()
@@ -192,12 +195,14 @@ class Tacotron2:
             _lib.check(lib.ttsx_encoder_convs_create(ctypes.byref(ew), _lib.current_stream(), ctypes.byref(eh)),
                        "ttsx_encoder_convs_create")
             self._enc_handle = eh
-        # encoder BiLSTM as a stock module
-        lstm = torch.nn.LSTM(512, 256, num_layers=1, batch_first=True, bidirectional=True)
-        with torch.no_grad():
-            for name, _ in lstm.named_parameters():
-                getattr(lstm, name).copy_(sd["encoder.lstm." + name])
-        self._lstm = lstm.to(dev).eval()
+            lw = _lib.EncoderLstmWeights()
+            for d, sfx in enumerate(("_l0", "_l0_reverse")):
+                lw.w_ih[d], lw.w_hh[d] = sd["encoder.lstm.weight_ih" + sfx].data_ptr(), sd["encoder.lstm.weight_hh" + sfx].data_ptr()
+                lw.b_ih[d], lw.b_hh[d] = sd["encoder.lstm.bias_ih" + sfx].data_ptr(), sd["encoder.lstm.bias_hh" + sfx].data_ptr()
+            lh = ctypes.c_void_p()
+            _lib.check(lib.ttsx_encoder_lstm_create(ctypes.byref(lw), _lib.current_stream(), ctypes.byref(lh)),
+                       "ttsx_encoder_lstm_create")
+            self._lstm_handle = lh
 
     def _require_device(self):
         if self.device.type != "cuda" or self._dec_handle is None:
@@ -208,9 +213,9 @@ class Tacotron2:
     @torch.no_grad()
     def encode(self, text, text_lengths=None):
         """Embedding + Encoder.inference (Tacotron2/TTS/models.py:803-804, 449-454).  The three
-        conv blocks run in the HIP conv-stack kernel (position-major, so the embedding output is
-        consumed as it is); the embedding lookup and the BiLSTM are stock ops.  With
-        `text_lengths` every utterance is encoded as its unpadded batch-1 run would be."""
+        conv blocks (position-major, so the embedding output is consumed as it is) and the BiLSTM
+        run in HIP kernels; the embedding lookup is a stock op.  With `text_lengths` every
+        utterance is encoded as its unpadded batch-1 run would be."""
         lib = _lib.load()
         sd = self._sd
         x = F.embedding(text, sd["embedding.weight"]).contiguous()          # [B,T,512]
@@ -219,17 +224,13 @@ class Tacotron2:
         lens = None
         if text_lengths is not None:
             lens = torch.as_tensor(text_lengths).to(device=x.device, dtype=torch.int32).contiguous()
+        out = torch.empty_like(x)
         with torch.cuda.device(x.device):
             _lib.check(lib.ttsx_encoder_convs_run(self._enc_handle, _lib.ptr(x), _lib.ptr(lens), B, T, _lib.ptr(y),
                                                   _lib.current_stream()), "ttsx_encoder_convs_run")
-        if lens is None:
-            out, _ = self._lstm(y)
-            return out.contiguous()
-        packed = torch.nn.utils.rnn.pack_padded_sequence(y, lens.cpu().long(), batch_first=True,
-                                                         enforce_sorted=False)
-        out, _ = self._lstm(packed)
-        out, _ = torch.nn.utils.rnn.pad_packed_sequence(out, batch_first=True, total_length=T)
-        return out.contiguous()
+            _lib.check(lib.ttsx_encoder_lstm_run(self._lstm_handle, _lib.ptr(y), _lib.ptr(lens), B, T, _lib.ptr(out),
+                                                 _lib.current_stream()), "ttsx_encoder_lstm_run")
+        return out
 
     @torch.no_grad()
     def decode(self, enc, enc_len=None, fixed_steps=None):
