@@ -59,6 +59,39 @@ struct ConvP {
   int x_pitch, y_pitch, y_off, r_pitch;
 };
 
+// Bias, activation, residual and store of one 32 x 32 tile (32-row block cb, the lane's frame).
+static __device__ __forceinline__ void store_tile(const ConvP& p, int cb, const f32x16& acc, int bb, int ff, int half) {
+  if (bb >= p.B) return;
+  const size_t frow = (size_t)bb * p.F + ff;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int co = cb * 32 + 8 * g + 4 * half;
+    if (co >= p.Cout) continue;
+    const float4 bv = *reinterpret_cast<const float4*>(p.bias + co);
+    float v[4] = {acc[4 * g] + bv.x, acc[4 * g + 1] + bv.y, acc[4 * g + 2] + bv.z, acc[4 * g + 3] + bv.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (p.act == ACT_TANH) v[e] = tanhf(v[e]);
+      else if (p.act == ACT_RELU) v[e] = fmaxf(v[e], 0.f);
+      else if (p.act == ACT_SIGMOID) v[e] = sigmoidf_(v[e]);
+    }
+    if (p.residual) {
+      const float* r = p.residual + frow * p.r_pitch + co;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += r[e];
+    }
+    float* dst = p.y + frow * p.y_pitch + p.y_off + co;
+    // a channel count that is not a multiple of 4 (1025 linear bins) ends in a partial quad
+    if (co + 3 < p.Cout && ((p.y_pitch | p.y_off) & 3) == 0) {
+      *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (co + e < p.Cout) dst[e] = v[e];
+    }
+  }
+}
+
 // Block = 4 waves as 2 (Cout) x 2 (frames); each wave owns a 64 x 64 output tile held as
 // 2 x 2 accumulators of 32 x 32.  Block tile: 128 channels x 128 frames.
 static __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvP p) {
@@ -128,38 +161,56 @@ static __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvP p) {
   for (int i = 0; i < 2; ++i) {
     if (!has_cb[i]) continue;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      if (bb[j] >= p.B) continue;
-      const size_t frow = (size_t)bb[j] * p.F + ff[j];
+    for (int j = 0; j < 2; ++j) store_tile(p, cb0 + i, acc[i][j], bb[j], ff[j], half);
+  }
+}
+
+// Small problems (few frames): the big tiling would leave the chip empty and walk K serially in
+// one wave.  Here a block owns ONE 32 x 32 output tile and its four waves split K (wave w takes
+// chunks w, w+4, ...; four chunks of loads in flight per wave), partial tiles summed through LDS.
+static __global__ __launch_bounds__(256) void conv_mfma_small_kernel(ConvP p) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int cb = blockIdx.y;
+  const long n = (long)blockIdx.x * 32 + l31;
+  const int bb = (int)(n / p.F), ff = (int)(n % p.F);
+  const int nf = bb < p.B ? (p.n_frames ? p.n_frames[bb] : p.F) : 0;
+  __shared__ f32x16 red[4][64];
+  f32x16 acc;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int co = (cb0 + i) * 32 + 8 * g + 4 * half;
-        if (co >= p.Cout) continue;
-        const float4 bv = *reinterpret_cast<const float4*>(p.bias + co);
-        float v[4] = {acc[i][j][4 * g] + bv.x, acc[i][j][4 * g + 1] + bv.y, acc[i][j][4 * g + 2] + bv.z,
-                      acc[i][j][4 * g + 3] + bv.w};
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  const float4* W = reinterpret_cast<const float4*>(p.wp) + (size_t)cb * p.NC * 64 + lane;
+  const int chunks_per_tap = p.Cin / 8;
+  constexpr int U = 4;
+  for (int c0 = wave * U; c0 < p.NC; c0 += 4 * U) {
+    float4 a[U], x[U];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          if (p.act == ACT_TANH) v[e] = tanhf(v[e]);
-          else if (p.act == ACT_RELU) v[e] = fmaxf(v[e], 0.f);
-          else if (p.act == ACT_SIGMOID) v[e] = sigmoidf_(v[e]);
-        }
-        if (p.residual) {
-          const float* r = p.residual + frow * p.r_pitch + co;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += r[e];
-        }
-        float* dst = p.y + frow * p.y_pitch + p.y_off + co;
-        // a channel count that is not a multiple of 4 (1025 linear bins) ends in a partial quad
-        if (co + 3 < p.Cout && ((p.y_pitch | p.y_off) & 3) == 0) {
-          *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (co + e < p.Cout) dst[e] = v[e];
-        }
+    for (int u = 0; u < U; ++u) {
+      const int c = c0 + u;
+      a[u] = make_float4(0.f, 0.f, 0.f, 0.f), x[u] = a[u];
+      if (c < p.NC) {
+        a[u] = W[(size_t)c * 64];
+        const int tap = c / chunks_per_tap, cc = c - tap * chunks_per_tap;
+        const int fs = ff + tap - p.pad_left;
+        if (fs >= 0 && fs < nf)
+          x[u] = *reinterpret_cast<const float4*>(p.x + ((size_t)bb * p.F + fs) * p.x_pitch + 4 * half + cc * 8);
       }
     }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].x, x[u].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].y, x[u].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].z, x[u].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].w, x[u].w, acc, 0, 0, 0);
+    }
+  }
+  red[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0) {
+    f32x16 v = red[0][lane];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) v += red[w][lane];
+    store_tile(p, cb, v, bb, ff, half);
   }
 }
 
@@ -201,7 +252,12 @@ static inline int layer_run(const Layer& L, const float* x, int x_pitch, float* 
   c.pad_left = L.pad_left, c.x_pitch = x_pitch, c.y_pitch = y_pitch, c.y_off = y_off, c.r_pitch = r_pitch;
   const long ncols = (long)B * F;
   dim3 grid((unsigned)((ncols + 127) / 128), ceil_div(L.cout, 128));
-  conv_mfma_kernel<<<grid, 256, 0, st>>>(c);
+  if ((long)grid.x * grid.y < 128) {
+    dim3 sgrid((unsigned)((ncols + 31) / 32), ceil_div(L.cout, 32));
+    conv_mfma_small_kernel<<<sgrid, 256, 0, st>>>(c);
+  } else {
+    conv_mfma_kernel<<<grid, 256, 0, st>>>(c);
+  }
   TTSX_LAUNCH_CHECK();
   return TTSX_OK;
 }
