@@ -491,7 +491,7 @@ struct AttnP {
   int gx;  // workgroups per utterance: workgroup id = b * gx + x
 };
 
-constexpr int EN_TT = 32, ATT_PAD = (LOC_K - 1) / 2;
+constexpr int ATT_PAD = (LOC_K - 1) / 2;
 
 // tanh through one hardware exponential: 1 - 2/(e^{2x}+1); saturates correctly at +-inf
 __device__ __forceinline__ float fast_tanhf(float x) {
@@ -499,12 +499,14 @@ __device__ __forceinline__ float fast_tanhf(float x) {
   return 1.f - 2.f * __builtin_amdgcn_rcpf(t + 1.f);
 }
 
-// energies e[b][t] for a tile of 32 encoder positions:
-//   cf[t][f] = sum_{c,j} W_lc[f][c][j] * a_c[t + j - 15]         (thread: filter f, 2 positions)
-//   e[t] = b_v + sum_d v[d] * tanh(q[d] + sum_f W_ld[d][f] cf[t][f] + P[t][d])   (thread: dim d, 8 positions)
+// energies e[b][t] for a tile of EN_TT (32, or 16 for small batches: more workgroups) encoder positions:
+//   cf[t][f] = sum_{c,j} W_lc[f][c][j] * a_c[t + j - 15]         (thread: filter f, EN_CP positions)
+//   e[t] = b_v + sum_d v[d] * tanh(q[d] + sum_f W_ld[d][f] cf[t][f] + P[t][d])   (thread: dim d, EN_DP positions)
 // Every global load of the kernel is issued before the first barrier, so the whole kernel costs
 // one memory round trip.
+template <int EN_TT>
 struct EnergyOp {
+  static constexpr int EN_CP = EN_TT / 16, EN_DP = EN_TT / 4;  // positions per thread in the conv / dense role
   typedef AttnP P;
   static __device__ __forceinline__ void run(const AttnP& p, int wg) {
   const int done = p.ctx->all_done;
@@ -521,11 +523,11 @@ struct EnergyOp {
     const float* src = c == 0 ? p.a_prev : p.a_cum;
     if (t >= 0 && t < T) a_in = src[(size_t)b * T + t];
   }
-  const int f = tid & 31, tp = tid >> 5;  // conv role: filter f, positions 2 tp, 2 tp + 1
+  const int f = tid & 31, tp = tid >> 5;  // conv role: filter f, positions EN_CP tp .. EN_CP tp + EN_CP - 1
   float wl[2 * LOC_K];
 #pragma unroll
   for (int j = 0; j < 2 * LOC_K; ++j) wl[j] = p.loc_conv_t[j * LOC_F + f];
-  const int d = tid & 127, tg = tid >> 7;  // dense role: dim d, positions tg*8 .. tg*8+7
+  const int d = tid & 127, tg = tid >> 7;  // dense role: dim d, positions tg*EN_DP .. tg*EN_DP+EN_DP-1
   float wd[LOC_F];
   {
     const float4* wsrc = reinterpret_cast<const float4*>(p.loc_dense_t) + d;
@@ -535,10 +537,10 @@ struct EnergyOp {
       wd[4 * i] = t4.x, wd[4 * i + 1] = t4.y, wd[4 * i + 2] = t4.z, wd[4 * i + 3] = t4.w;
     }
   }
-  float pin[8];
+  float pin[EN_DP];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int t = t0 + tg * 8 + i;
+  for (int i = 0; i < EN_DP; ++i) {
+    const int t = t0 + tg * EN_DP + i;
     pin[i] = t < T ? p.P[((size_t)b * T + t) * ATT_DIM + d] : 0.f;
   }
   const float qd = p.q[qidx(d, b, p.Bpad)], vd = p.v_w[d], vb = p.v_b[0];
@@ -546,25 +548,26 @@ struct EnergyOp {
   if (tid < 2 * (EN_TT + 2 * ATT_PAD)) s_a[tid / (EN_TT + 2 * ATT_PAD)][tid % (EN_TT + 2 * ATT_PAD)] = a_in;
   __syncthreads();
   {
-    float acc0 = 0.f, acc1 = 0.f;
+    float acc[EN_CP];
+#pragma unroll
+    for (int u = 0; u < EN_CP; ++u) acc[u] = 0.f;
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-      float win[LOC_K + 1];
+      float win[LOC_K + EN_CP - 1];
 #pragma unroll
-      for (int j = 0; j < LOC_K + 1; ++j) win[j] = s_a[c][tp * 2 + j];
+      for (int j = 0; j < LOC_K + EN_CP - 1; ++j) win[j] = s_a[c][tp * EN_CP + j];
 #pragma unroll
-      for (int j = 0; j < LOC_K; ++j) {
-        acc0 += wl[c * LOC_K + j] * win[j];
-        acc1 += wl[c * LOC_K + j] * win[j + 1];
-      }
+      for (int j = 0; j < LOC_K; ++j)
+#pragma unroll
+        for (int u = 0; u < EN_CP; ++u) acc[u] += wl[c * LOC_K + j] * win[j + u];
     }
-    s_cf[tp * 2][f] = acc0;
-    s_cf[tp * 2 + 1][f] = acc1;
+#pragma unroll
+    for (int u = 0; u < EN_CP; ++u) s_cf[tp * EN_CP + u][f] = acc[u];
   }
   __syncthreads();
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int tl = tg * 8 + i;
+  for (int i = 0; i < EN_DP; ++i) {
+    const int tl = tg * EN_DP + i;
     const float4* cf4 = reinterpret_cast<const float4*>(&s_cf[tl][0]);
     float loc = 0.f;
 #pragma unroll
@@ -1061,10 +1064,16 @@ int enqueue_step(ttsx_t2_decoder* d, int i, bool first, bool more, hipStream_t s
   ap.a_prev = d->a_prev, ap.a_cum = d->a_cum, ap.energies = d->energies, ap.ctx_out = d->ctx;
   ap.enc = d->enc_ws, ap.len = d->len_ws, ap.T = T;
   ap.ctx = d->rc, ap.step_in_chunk = i, ap.Bpad = Bpad, ap.norm = d->norm;
-  ap.gx = ceil_div(T, EN_TT);
   pc = pd.piece(1);
   pc.on = split;
-  if ((rc = launch_with_piece<EnergyOp, PK2>(d, ap, ap.gx * B, 0, &pc, st))) return rc;
+  if (B >= 16) {
+    ap.gx = ceil_div(T, 32);
+    rc = launch_with_piece<EnergyOp<32>, PK2>(d, ap, ap.gx * B, 0, &pc, st);
+  } else {
+    ap.gx = ceil_div(T, 16);
+    rc = launch_with_piece<EnergyOp<16>, PK2>(d, ap, ap.gx * B, 0, &pc, st);
+  }
+  if (rc) return rc;
   pc = pd.piece(2);
   pc.on = split;
   if (B >= 16) {
