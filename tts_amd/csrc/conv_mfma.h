@@ -124,37 +124,52 @@ static __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvP p) {
   const float4* W0 = reinterpret_cast<const float4*>(p.wp) + (size_t)(has_cb[0] ? cb0 : 0) * p.NC * 64 + lane;
   const float4* W1 = reinterpret_cast<const float4*>(p.wp) + (size_t)(has_cb[1] ? cb0 + 1 : 0) * p.NC * 64 + lane;
   const int chunks_per_tap = p.Cin / 8;
+  const float* xbase[2] = {p.x + (size_t)bb[0] * p.F * p.x_pitch + 4 * half, p.x + (size_t)bb[1] * p.F * p.x_pitch + 4 * half};
 
-  for (int tap = 0; tap < p.taps; ++tap) {
-    // source frame of each column tile for this tap
-    const float* xrow[2];
-    bool ok[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int fs = ff[j] + tap - p.pad_left;
-      ok[j] = fs >= 0 && fs < nf[j];
-      xrow[j] = p.x + ((size_t)bb[j] * p.F + (ok[j] ? fs : 0)) * p.x_pitch + 4 * half;
+  // operands of K chunk c (8 wide): two weight fragments, two activation fragments (zero outside the utterance)
+  struct Frag {
+    float4 a0, a1, x0, x1;
+  };
+  auto load = [&](int c, int tap, int cc) -> Frag {
+    Frag f;
+    f.a0 = make_float4(0.f, 0.f, 0.f, 0.f), f.a1 = f.a0, f.x0 = f.a0, f.x1 = f.a0;
+    if (c < p.NC) {
+      f.a0 = W0[(size_t)c * 64];
+      f.a1 = W1[(size_t)c * 64];
+      const int fs0 = ff[0] + tap - p.pad_left, fs1 = ff[1] + tap - p.pad_left;
+      if (fs0 >= 0 && fs0 < nf[0]) f.x0 = *reinterpret_cast<const float4*>(xbase[0] + (size_t)fs0 * p.x_pitch + cc * 8);
+      if (fs1 >= 0 && fs1 < nf[1]) f.x1 = *reinterpret_cast<const float4*>(xbase[1] + (size_t)fs1 * p.x_pitch + cc * 8);
     }
-    const int cbase = tap * chunks_per_tap;
-#pragma unroll 2
-    for (int cc = 0; cc < chunks_per_tap; ++cc) {
-      const float4 a0 = W0[(size_t)(cbase + cc) * 64];
-      const float4 a1 = W1[(size_t)(cbase + cc) * 64];
-      float4 x0 = make_float4(0.f, 0.f, 0.f, 0.f), x1 = x0;
-      if (ok[0]) x0 = *reinterpret_cast<const float4*>(xrow[0] + cc * 8);
-      if (ok[1]) x1 = *reinterpret_cast<const float4*>(xrow[1] + cc * 8);
+    return f;
+  };
 #define TTSX_MFMA4(A, X, ACC)                                         \
   ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(A.x, X.x, ACC, 0, 0, 0); \
   ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(A.y, X.y, ACC, 0, 0, 0); \
   ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(A.z, X.z, ACC, 0, 0, 0); \
   ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(A.w, X.w, ACC, 0, 0, 0);
-      TTSX_MFMA4(a0, x0, acc[0][0]);
-      TTSX_MFMA4(a0, x1, acc[0][1]);
-      TTSX_MFMA4(a1, x0, acc[1][0]);
-      TTSX_MFMA4(a1, x1, acc[1][1]);
-#undef TTSX_MFMA4
-    }
+  auto mma = [&](const Frag& f) {
+    TTSX_MFMA4(f.a0, f.x0, acc[0][0]);
+    TTSX_MFMA4(f.a0, f.x1, acc[0][1]);
+    TTSX_MFMA4(f.a1, f.x0, acc[1][0]);
+    TTSX_MFMA4(f.a1, f.x1, acc[1][1]);
+  };
+  // software pipeline over the K chunks (tap-major): the operands of chunk c+1 are requested before
+  // the 16 MFMAs of chunk c issue
+  int tap = 0, cc = 0;
+  auto advance = [&]() {
+    if (++cc == chunks_per_tap) cc = 0, ++tap;
+  };
+  Frag fa = load(0, tap, cc);
+  advance();
+  for (int c = 0; c < p.NC; c += 2) {
+    Frag fb = load(c + 1, tap, cc);
+    advance();
+    mma(fa);
+    fa = load(c + 2, tap, cc);
+    advance();
+    mma(fb);
   }
+#undef TTSX_MFMA4
 
   // epilogue: lane holds column l31 (a frame) and rows 8g + 4*half + {0..3} of each 32-row block
 #pragma unroll
