@@ -124,3 +124,17 @@ def test_vocoder_argument_errors():
     bad = _lib.StftParams(1024, 275, 1100, 0)
     rc = lib.ttsx_griffin_lim(_lib.ptr(x), _lib.ptr(x), None, 1, 4, bad, 1, 0.98, _lib.ptr(w), _lib.current_stream())
     assert rc == _lib.ERR_ARG and b"n_fft" in lib.ttsx_last_error_string()
+
+
+def test_griffin_lim_two_frames_and_zero_iterations():
+    """The shortest legal utterance (two frames = one hop of signal) and iters = 0 (one ISTFT of
+    the initial phase)."""
+    from tts_amd import synthetic
+    for iters in (0, 3):
+        orc, ap = _aps(False, iters=iters)
+        S = np.abs(_smooth_mel(3, 1025, 2, 1.0)).astype(np.float32)
+        ph = synthetic.gl_init_phase(4, 1025, 2)
+        y_ref = orc._griffin_lim(S, ph)
+        y = ap._griffin_lim(S, init_phase=ph)
+        assert y.shape == y_ref.shape == (ap.hop_length,)
+        assert _snr_db(y_ref, y) >= 40.0
