@@ -3,6 +3,8 @@
 Usage (from the repo root, in the container that mounts /root/reference):
 
     python oracle/gen_golden.py t2      # Tacotron2 model fixtures
+    python oracle/gen_golden.py t2v     # Tacotron2 optional variants (windowing, forward / Graves
+                                        # attention, speaker embedding, inference_truncated)
     python oracle/gen_golden.py t2audio # AudioProcessor pieces that run without librosa
     python oracle/gen_golden.py t1      # Tacotron (v1) model fixtures
 
@@ -102,6 +104,73 @@ def gen_t2():
                                                   float(stop[0, :-1, 0].max()) if stop.shape[1] > 1 else 0))
 
 
+# ------------------------------------------------------------------ Tacotron2 optional variants
+T2V_CASES = [
+    # name, attn_norm, T_in, ids_seed, max_decoder_steps, constructor options, gains
+    ("t2v_window_softmax_T60", "softmax", 60, 31, 40, dict(attn_win=True), {"stop_bias": -30.0}),
+    ("t2v_window_sigmoid_T33", "sigmoid", 33, 32, 30, dict(attn_win=True), {"stop_bias": -30.0}),
+    ("t2v_fwd_sigmoid_T50", "sigmoid", 50, 33, 40, dict(forward_attn=True), {"stop_bias": -30.0}),
+    ("t2v_fwd_mask_agent_softmax_T50", "softmax", 50, 34, 14,
+     dict(forward_attn=True, trans_agent=True, forward_attn_mask=True), {"stop_bias": -30.0}),
+    ("t2v_fwd_mask_sigmoid_T9", "sigmoid", 9, 35, 24, dict(forward_attn=True, forward_attn_mask=True),
+     {"stop_bias": -30.0}),
+    ("t2v_noloc_softmax_T40", "softmax", 40, 36, 30, dict(location_attn=False), {"stop_bias": -30.0}),
+    ("t2v_graves_T60", "softmax", 60, 37, 40, dict(attn_type="graves", attn_K=5), {"stop_bias": -30.0}),
+    ("t2v_speaker_T30", "sigmoid", 30, 38, 3000, dict(num_speakers=4, speaker_id=2), {}),
+    ("t2v_speaker_T44_max20", "softmax", 44, 39, 20, dict(num_speakers=4, speaker_id=3), {"stop_bias": -30.0}),
+]
+
+
+def _t2_variant_model(Tacotron2, norm, opts, gains):
+    opts = dict(opts)
+    speaker_id = opts.pop("speaker_id", None)
+    num_speakers = opts.pop("num_speakers", 0)
+    sd = synthetic.t2_state_dict(seed=0, gains=gains, attn_type=opts.get("attn_type", "original"),
+                                 location_attn=opts.get("location_attn", True),
+                                 trans_agent=opts.get("trans_agent", False), attn_K=opts.get("attn_K", 5),
+                                 num_speakers=num_speakers)
+    model = Tacotron2(num_chars=129, num_speakers=num_speakers, r=7, attn_norm=norm, prenet_type="bn",
+                      prenet_dropout=False, separate_stopnet=True, **opts)
+    model.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
+    model.eval()
+    return model, speaker_id
+
+
+def gen_t2v():
+    sys.path.insert(0, os.path.join(REF, "Tacotron2"))
+    from TTS.models import Tacotron2  # the reference implementation
+    for name, norm, T, ids_seed, max_steps, opts, gains in T2V_CASES:
+        model, speaker_id = _t2_variant_model(Tacotron2, norm, opts, gains)
+        model.decoder.max_decoder_steps = max_steps
+        model.decoder.set_r(1)
+        ids = synthetic.t2_text_ids(ids_seed, 1, T)
+        spk = None if speaker_id is None else torch.as_tensor([speaker_id])
+        with torch.no_grad():
+            dec, post, align, stop = model.inference(torch.as_tensor(ids), speaker_ids=spk)
+        meta = dict(attn_norm=norm, prenet_type="bn", r=1, r_init=7, weight_seed=0, gains=gains, ids_seed=ids_seed,
+                    T_in=T, max_decoder_steps=max_steps, options=opts)
+        np.savez_compressed(os.path.join(GOLD, name + ".npz"), meta=json.dumps(meta), ids=ids,
+                            decoder_output=dec.numpy(), postnet_output=post.numpy(),
+                            alignments=align.numpy(), stop_tokens=stop.numpy())
+        al = align[0].numpy()
+        print(name, "steps", align.shape[1], "argmax path", al.argmax(-1)[:12], "max", float(al.max()))
+    # inference_truncated: three consecutive calls on one model (state carried across calls)
+    model, _ = _t2_variant_model(Tacotron2, "sigmoid", {}, {"stop_bias": -30.0})
+    model.decoder.max_decoder_steps = 12
+    model.decoder.set_r(1)
+    out = {}
+    for i, (T, seed) in enumerate(((21, 41), (34, 42), (13, 43))):
+        ids = synthetic.t2_text_ids(seed, 1, T)
+        with torch.no_grad():
+            dec, post, align, stop = model.inference_truncated(torch.as_tensor(ids))
+        out.update({"ids%d" % i: ids, "decoder_output%d" % i: dec.numpy(), "postnet_output%d" % i: post.numpy(),
+                    "alignments%d" % i: align.numpy(), "stop_tokens%d" % i: stop.numpy()})
+        print("t2v_truncated call", i, "steps", align.shape[1])
+    meta = dict(attn_norm="sigmoid", prenet_type="bn", r=1, r_init=7, weight_seed=0, gains={"stop_bias": -30.0},
+                max_decoder_steps=12, n_calls=3)
+    np.savez_compressed(os.path.join(GOLD, "t2v_truncated.npz"), meta=json.dumps(meta), **out)
+
+
 # ------------------------------------------------------------------ Tacotron2 AudioProcessor pieces
 def gen_t2audio():
     _register_placeholders()
@@ -175,4 +244,4 @@ def gen_t1():
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    {"t2": gen_t2, "t2audio": gen_t2audio, "t1": gen_t1}[sys.argv[1]]()
+    {"t2": gen_t2, "t2v": gen_t2v, "t2audio": gen_t2audio, "t1": gen_t1}[sys.argv[1]]()

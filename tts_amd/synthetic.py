@@ -109,11 +109,15 @@ def _lstm(sd, seed, prefix, in_dim, hid, gain, suffix=""):
         sd[key] = uniform(seed, key, shape, -a, a)
 
 
-def t2_state_dict(seed=0, num_chars=129, r_init=7, prenet_type="bn", gains=None):
+def t2_state_dict(seed=0, num_chars=129, r_init=7, prenet_type="bn", gains=None, attn_type="original",
+                  location_attn=True, trans_agent=False, attn_K=5, num_speakers=0):
     """Synthetic Tacotron2 `state_dict` (NumPy arrays, reference key names).
 
     Shapes follow the reference constructor (Tacotron2/TTS/models.py:755-771,
-    489-524, 405-412, 422-431)."""
+    489-524, 405-412, 422-431).  The optional arguments add or drop the tensors of the
+    attention variants exactly as the reference constructor does (:113-130 Graves N_a,
+    :204-212 transition agent / location layer, :759-761 speaker embedding); the default
+    arguments give the same bits as before those options existed."""
     g = dict(T2_GAINS)
     if gains:
         g.update(gains)
@@ -133,17 +137,34 @@ def t2_state_dict(seed=0, num_chars=129, r_init=7, prenet_type="bn", gains=None)
         if prenet_type == "bn":
             _bn(sd, seed, p + ".bn", 256)
     _lstm(sd, seed, "decoder.attention_rnn", 768, 1024, g["lstm"])
-    sd["decoder.attention.query_layer.linear_layer.weight"] = _xavier(
-        seed, "att.query", (128, 1024), g["query"] * 5.0 / 3.0)
-    sd["decoder.attention.inputs_layer.linear_layer.weight"] = _xavier(
-        seed, "att.inputs", (128, 512), g["inputs"] * 5.0 / 3.0)
-    sd["decoder.attention.v.linear_layer.weight"] = _xavier(seed, "att.v", (1, 128), g["v"])
-    sd["decoder.attention.v.linear_layer.bias"] = uniform(seed, "att.v.b", (1,), -0.1, 0.1)
-    a = g["loc"] / np.sqrt(2 * 31)
-    sd["decoder.attention.location_layer.location_conv.weight"] = uniform(
-        seed, "att.loc_conv", (32, 2, 31), -a, a)
-    sd["decoder.attention.location_layer.location_dense.linear_layer.weight"] = _xavier(
-        seed, "att.loc_dense", (128, 32), 5.0 / 3.0)
+    if attn_type == "graves":
+        a = 1.0 / np.sqrt(1024.0)
+        sd["decoder.attention.N_a.0.weight"] = uniform(seed, "att.N_a.0.w", (1024, 1024), -3 * a, 3 * a)
+        sd["decoder.attention.N_a.0.bias"] = uniform(seed, "att.N_a.0.b", (1024,), -a, a)
+        sd["decoder.attention.N_a.2.weight"] = uniform(seed, "att.N_a.2.w", (3 * attn_K, 1024), -a, a)
+        b2 = uniform(seed, "att.N_a.2.b", (3 * attn_K,), -a, a)
+        # GravesAttention.init_layers (:128-130) starts the std bias at 10 (alignments nearly flat
+        # over a short text); 0.5 here so that the mixture is narrow enough to test the arithmetic
+        b2[attn_K:2 * attn_K] = 0.5
+        b2[2 * attn_K:] = 1.0             # bias mean
+        sd["decoder.attention.N_a.2.bias"] = b2
+    else:
+        sd["decoder.attention.query_layer.linear_layer.weight"] = _xavier(
+            seed, "att.query", (128, 1024), g["query"] * 5.0 / 3.0)
+        sd["decoder.attention.inputs_layer.linear_layer.weight"] = _xavier(
+            seed, "att.inputs", (128, 512), g["inputs"] * 5.0 / 3.0)
+        sd["decoder.attention.v.linear_layer.weight"] = _xavier(seed, "att.v", (1, 128), g["v"])
+        sd["decoder.attention.v.linear_layer.bias"] = uniform(seed, "att.v.b", (1,), -0.1, 0.1)
+        if trans_agent:
+            a = 4.0 / np.sqrt(1536.0)
+            sd["decoder.attention.ta.weight"] = uniform(seed, "att.ta.w", (1, 1536), -a, a)
+            sd["decoder.attention.ta.bias"] = uniform(seed, "att.ta.b", (1,), -0.5, 0.5)
+        if location_attn:
+            a = g["loc"] / np.sqrt(2 * 31)
+            sd["decoder.attention.location_layer.location_conv.weight"] = uniform(
+                seed, "att.loc_conv", (32, 2, 31), -a, a)
+            sd["decoder.attention.location_layer.location_dense.linear_layer.weight"] = _xavier(
+                seed, "att.loc_dense", (128, 32), 5.0 / 3.0)
     _lstm(sd, seed, "decoder.decoder_rnn", 1536, 1024, g["lstm"])
     sd["decoder.linear_projection.linear_layer.weight"] = _xavier(
         seed, "dec.proj", (80 * r_init, 1536), g["proj"])
@@ -156,6 +177,8 @@ def t2_state_dict(seed=0, num_chars=129, r_init=7, prenet_type="bn", gains=None)
     chans = [80, 512, 512, 512, 512, 80]
     for i in range(5):
         _conv_bn(sd, seed, "postnet.convolutions.%d" % i, chans[i + 1], chans[i], 5, g["conv"])
+    if num_speakers > 1:
+        sd["speaker_embedding.weight"] = normal(seed, "speaker_embedding.weight", (num_speakers, 512), 0.0, 0.3)
     return sd
 
 
