@@ -84,6 +84,41 @@ int ttsx_t2_decoder_create(const ttsx_t2_decoder_weights* w, int r_init, int att
                            void* stream, ttsx_t2_decoder** out);
 int ttsx_t2_decoder_destroy(ttsx_t2_decoder* dec);
 
+/* Optional attention variants of the reference (all off in the repo's config.json:84-92):
+ *   location_attn = false  OriginalAttention.get_attention (models.py:269-273): hand NULL for
+ *                          loc_conv_w / loc_dense_w in ttsx_t2_decoder_weights;
+ *   windowing              apply_windowing at inference (models.py:275-288; window = [idx-2, idx+6),
+ *                          idx = argmax of the windowed energies, per utterance);
+ *   forward_attn           apply_forward_attention (models.py:290-312), with forward_attn_mask its
+ *                          inference-time masking (the index arithmetic is Python's: n-1 / n-2 may
+ *                          wrap to the end of the utterance) and with trans_agent the transition
+ *                          probability u = sigmoid(ta [context; query]) (models.py:357-360);
+ *   graves_K > 0           GravesAttention with K mixtures (models.py:106-183) instead of the
+ *                          original attention: query_w / inputs_w / v_w / v_b / loc_* may be NULL.
+ * Call after create and before begin/run; tensors are copied.  Synchronises `stream`. */
+typedef struct {
+  int windowing;          /* config "windowing" */
+  int forward_attn;       /* config "use_forward_attn" */
+  int forward_attn_mask;  /* config "forward_attn_mask" */
+  int trans_agent;        /* config "transition_agent" */
+  const float* ta_w;      /* attention.ta.weight [1,1536] (input = [context 512; query 1024]) */
+  const float* ta_b;      /* attention.ta.bias   [1] */
+  int graves_K;           /* config "attention_heads" when attention_type is "graves", else 0; <= 16 */
+  const float* graves_w1; /* attention.N_a.0.weight [1024,1024] */
+  const float* graves_b1; /* attention.N_a.0.bias   [1024] */
+  const float* graves_w2; /* attention.N_a.2.weight [3K,1024] */
+  const float* graves_b2; /* attention.N_a.2.bias   [3K] */
+} ttsx_t2_attention_options;
+int ttsx_t2_decoder_set_attention(ttsx_t2_decoder* dec, const ttsx_t2_attention_options* opt, void* stream);
+
+/* One-shot settings of the NEXT begin()/run() (Decoder.inference_truncated, models.py:675-709):
+ *   keep_states  non-zero: the LSTM states and the context of the previous run survive
+ *                (Decoder._init_states(keep_states=True), models.py:536-552); the attention state
+ *                is reset as always.  The previous run must have had the same B.
+ *   memory       [B,80] frame fed to the first step instead of the all-zero go frame
+ *                (memory_truncated, models.py:690,703), copied at call time; or NULL. */
+int ttsx_t2_decoder_set_initial(ttsx_t2_decoder* dec, int keep_states, const float* memory, int B, void* stream);
+
 /* Greedy decode of B utterances (Decoder.inference, models.py:643-673).
  *   enc      [B,T,512]  encoder outputs
  *   enc_len  [B] int32 valid encoder length per utterance, or NULL (= T for all);
@@ -193,6 +228,17 @@ int ttsx_encoder_lstm_destroy(ttsx_encoder_lstm* p);
  *   out      [B,T,512] = [forward 256 | backward 256]                                    */
 int ttsx_encoder_lstm_run(ttsx_encoder_lstm* p, const float* x, const int32_t* lengths, int B, int T, float* out,
                           void* stream);
+
+/* Encoder.inference_truncated (models.py:456-464): the BiLSTM starts from a carried state and
+ * returns the final one.  h_state / c_state [2][B][256] (index 0 forward, 1 reverse: nn.LSTM's
+ * (h_n, c_n) layout), read and overwritten; both NULL = ttsx_encoder_lstm_run.  lengths must be NULL. */
+int ttsx_encoder_lstm_run_stateful(ttsx_encoder_lstm* p, const float* x, const int32_t* lengths, int B, int T,
+                                   float* out, float* h_state, float* c_state, void* stream);
+
+/* Tacotron2._add_speaker_embedding (models.py:838-849): enc[b][t][:] += table[speaker_ids[b]][:].
+ *   enc [B,T,512] in place, table = speaker_embedding.weight [n_speakers,512], speaker_ids [B] int32. */
+int ttsx_add_speaker_embedding(float* enc, const float* table, const int32_t* speaker_ids, int n_speakers, int B,
+                               int T, void* stream);
 
 /* ------------------------------------------------------------------ Tacotron (v1)
  * Replaces Tacotron.forward in eval mode, Tacotron/TTS/models.py:692-700:

@@ -29,6 +29,12 @@ class T2DecoderWeights(Structure):
     ]
 
 
+class T2AttentionOptions(Structure):
+    _fields_ = [("windowing", c_int), ("forward_attn", c_int), ("forward_attn_mask", c_int), ("trans_agent", c_int),
+                ("ta_w", _fp), ("ta_b", _fp), ("graves_K", c_int),
+                ("graves_w1", _fp), ("graves_b1", _fp), ("graves_w2", _fp), ("graves_b2", _fp)]
+
+
 class PostnetWeights(Structure):
     _fields_ = [("conv_w", _fp * 5), ("conv_b", _fp * 5), ("bn_weight", _fp * 5), ("bn_bias", _fp * 5),
                 ("bn_mean", _fp * 5), ("bn_var", _fp * 5)]
@@ -87,6 +93,8 @@ PROTOTYPES = {
     "ttsx_version": (c_int, []),
     "ttsx_t2_decoder_create": (c_int, [POINTER(T2DecoderWeights), c_int, c_int, c_void_p, POINTER(c_void_p)]),
     "ttsx_t2_decoder_destroy": (c_int, [c_void_p]),
+    "ttsx_t2_decoder_set_attention": (c_int, [c_void_p, POINTER(T2AttentionOptions), c_void_p]),
+    "ttsx_t2_decoder_set_initial": (c_int, [c_void_p, c_int, _fp, c_int, c_void_p]),
     "ttsx_t2_decoder_run": (c_int, [c_void_p, _fp, _fp, c_int, c_int, c_int, c_int, c_float, c_int, _fp, _fp,
                                     _fp, _fp, POINTER(c_int), c_void_p]),
     "ttsx_t2_decoder_begin": (c_int, [c_void_p, _fp, _fp, c_int, c_int, c_void_p]),
@@ -102,6 +110,8 @@ PROTOTYPES = {
     "ttsx_encoder_lstm_create": (c_int, [POINTER(EncoderLstmWeights), c_void_p, POINTER(c_void_p)]),
     "ttsx_encoder_lstm_destroy": (c_int, [c_void_p]),
     "ttsx_encoder_lstm_run": (c_int, [c_void_p, _fp, _fp, c_int, c_int, _fp, c_void_p]),
+    "ttsx_encoder_lstm_run_stateful": (c_int, [c_void_p, _fp, _fp, c_int, c_int, _fp, _fp, _fp, c_void_p]),
+    "ttsx_add_speaker_embedding": (c_int, [_fp, _fp, _fp, c_int, c_int, c_int, c_void_p]),
     "ttsx_t1_create": (c_int, [POINTER(T1Weights), c_int, c_int, c_int, c_void_p, POINTER(c_void_p)]),
     "ttsx_t1_destroy": (c_int, [c_void_p]),
     "ttsx_t1_encoder_run": (c_int, [c_void_p, _fp, _fp, c_int, c_int, _fp, c_void_p]),

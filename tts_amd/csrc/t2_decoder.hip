@@ -489,6 +489,17 @@ struct AttnP {
   RunCtx* ctx;
   int step_in_chunk, Bpad, norm, T;
   int gx;  // workgroups per utterance: workgroup id = b * gx + x
+  // optional attention variants (AttnPostOp / GravesOp only)
+  int windowing, forward_attn, forward_attn_mask, trans_agent;
+  int32_t* win_idx;     // [B] window centre of apply_windowing, -1 before the first step
+  float* alpha;         // [B][T] forward-attention state
+  float* u;             // [B] transition probability of forward attention
+  const float* ta_w;    // [1536] transition agent: [context 512; query 1024]
+  const float* ta_b;    // [1]
+  const float* h_new;   // quad [1024]: attention-LSTM hidden state of this step (the "query")
+  const float* gbk;     // quad [3K]: output of GravesAttention.N_a for this step
+  float* mu;            // [B][K] means of the Graves mixture
+  int graves_K;
 };
 
 constexpr int ATT_PAD = (LOC_K - 1) / 2;
@@ -679,6 +690,257 @@ struct ContextOp {
   }
 };
 
+// ---- workgroup-wide reductions for the one-workgroup-per-utterance attention variants
+// (`s_red` / `s_redi`: one slot per wave; every thread gets the result)
+__device__ __forceinline__ float block_sum(float v, float* s_red) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int w = 0; w < CTX_THREADS / 64; ++w) t += s_red[w];
+  return t;
+}
+__device__ __forceinline__ float block_max(float v, float* s_red) {
+  v = wave_max(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float t = s_red[0];
+  for (int w = 1; w < CTX_THREADS / 64; ++w) t = fmaxf(t, s_red[w]);
+  return t;
+}
+// index of the first maximum of x[0..n) (what torch.argmax / torch.max(dim) return on the CPU)
+__device__ __forceinline__ int block_argmax_first(const float* x, int n, float* s_red, int* s_redi, float* max_out) {
+  float bv = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int t = threadIdx.x; t < n; t += CTX_THREADS) {
+    const float v = x[t];
+    if (v > bv || (v == bv && t < bi)) bv = v, bi = t;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float ov = __shfl_xor(bv, off, 64);
+    const int oi = __shfl_xor(bi, off, 64);
+    if (ov > bv || (ov == bv && oi < bi)) bv = ov, bi = oi;
+  }
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = bv, s_redi[threadIdx.x >> 6] = bi;
+  __syncthreads();
+  bv = s_red[0], bi = s_redi[0];
+  for (int w = 1; w < CTX_THREADS / 64; ++w)
+    if (s_red[w] > bv || (s_red[w] == bv && s_redi[w] < bi)) bv = s_red[w], bi = s_redi[w];
+  if (max_out) *max_out = bv;
+  return bi;
+}
+
+// context of one utterance by one workgroup: ctx[c] = sum_t a[t] enc[t][c] for all 512 columns,
+// written in quad layout and left in s_ctx[512]
+__device__ __forceinline__ void block_context(const AttnP& p, int b, int len, const float* s_al, float4* s_acc,
+                                              float* s_ctx) {
+  const int tid = threadIdx.x, T = p.T;
+  constexpr int LPR = ENC_DIM / 4, RG = CTX_THREADS / LPR;
+  const int cl = tid % LPR, rg = tid / LPR;
+  const float4* e4 = reinterpret_cast<const float4*>(p.enc + (size_t)b * T * ENC_DIM) + cl;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int t = rg; t < len; t += RG) {
+    const float4 v0 = e4[(size_t)t * (ENC_DIM / 4)];
+    const float a0 = s_al[t];
+    acc.x += a0 * v0.x, acc.y += a0 * v0.y, acc.z += a0 * v0.z, acc.w += a0 * v0.w;
+  }
+  __syncthreads();
+  s_acc[tid] = acc;
+  __syncthreads();
+  if (tid < LPR) {
+    float4 tot = s_acc[tid];
+    for (int g = 1; g < RG; ++g) {
+      const float4 v = s_acc[g * LPR + tid];
+      tot.x += v.x, tot.y += v.y, tot.z += v.z, tot.w += v.w;
+    }
+    reinterpret_cast<float4*>(p.ctx_out)[(size_t)tid * p.Bpad + b] = tot;
+    reinterpret_cast<float4*>(s_ctx)[tid] = tot;
+  }
+  __syncthreads();
+}
+
+// Everything OriginalAttention.forward does after the energies, with its optional branches
+// (Tacotron2/TTS/models.py:328-361): length mask, apply_windowing (:275-288), normalisation,
+// cumulative weights, apply_forward_attention (:290-312) with the transition agent (:357-360),
+// context.  One workgroup per utterance; every utterance keeps its own window index (the
+// reference evaluates it on utterance 0 and only runs at batch 1).
+struct AttnPostOp {
+  typedef AttnP P;
+  static __device__ __forceinline__ void run(const AttnP& p, int wg) {
+    RunCtx* cx = p.ctx;
+    const int done = cx->all_done;
+    const int T = p.T, b = wg, tid = threadIdx.x;
+    const int len = p.len[b];
+    extern __shared__ float s_dyn[];
+    float* s_e = s_dyn;           // [T] energies, then scratch
+    float* s_al = s_dyn + T;      // [T] alignment
+    float* s_old = s_dyn + 2 * T; // [T] previous forward-attention weights
+    __shared__ float s_red[CTX_THREADS / 64];
+    __shared__ int s_redi[CTX_THREADS / 64];
+    __shared__ float4 s_acc[CTX_THREADS];
+    __shared__ __attribute__((aligned(16))) float s_ctx[ENC_DIM];
+
+    for (int t = tid; t < T; t += CTX_THREADS) s_e[t] = t < len ? p.energies[(size_t)b * T + t] : -INFINITY;
+    __syncthreads();
+    if (p.windowing) {
+      const int w = p.win_idx[b], back = w - 2, front = w + 6;
+      for (int t = tid; t < len; t += CTX_THREADS)
+        if ((back > 0 && t < back) || (front < len && t >= front)) s_e[t] = -INFINITY;
+      __syncthreads();
+      if (w == -1) {
+        float m = -INFINITY;
+        for (int t = tid; t < len; t += CTX_THREADS) m = fmaxf(m, s_e[t]);
+        m = block_max(m, s_red);
+        if (tid == 0) s_e[0] = m;
+        __syncthreads();
+      }
+      const int idx = block_argmax_first(s_e, len, s_red, s_redi, nullptr);
+      if (tid == 0 && !done) p.win_idx[b] = idx;
+    }
+    const bool softmax = p.norm == TTSX_NORM_SOFTMAX;
+    float m = 0.f;
+    if (softmax) {
+      m = -INFINITY;
+      for (int t = tid; t < len; t += CTX_THREADS) m = fmaxf(m, s_e[t]);
+      m = block_max(m, s_red);
+    }
+    float sum = 0.f;
+    for (int t = tid; t < T; t += CTX_THREADS) {
+      float v = 0.f;
+      if (t < len) v = softmax ? expf(s_e[t] - m) : sigmoidf_(s_e[t]);
+      s_al[t] = v;
+      sum += v;
+    }
+    sum = block_sum(sum, s_red);
+    for (int t = tid; t < T; t += CTX_THREADS) {
+      const float a = s_al[t] / sum;
+      s_al[t] = a;
+      if (!done) p.a_cum[(size_t)b * T + t] += a;
+    }
+    __syncthreads();
+    if (p.forward_attn) {
+      const float u = p.u[b];
+      for (int t = tid; t < T; t += CTX_THREADS) s_old[t] = t < len ? p.alpha[(size_t)b * T + t] : 0.f;
+      __syncthreads();
+      // s_e <- shifted weights, s_al <- transition potentials
+      float vmax = -INFINITY;
+      for (int t = tid; t < len; t += CTX_THREADS) {
+        const float sh = t == 0 ? 0.f : s_old[t - 1];
+        s_e[t] = sh;
+        const float v = ((1.f - u) * s_old[t] + u * sh + 1e-8f) * s_al[t];
+        s_al[t] = v;
+        vmax = fmaxf(vmax, v);
+      }
+      __syncthreads();
+      if (p.forward_attn_mask) {
+        const float val = block_max(vmax, s_red);
+        const int n = block_argmax_first(s_e, len, s_red, s_redi, nullptr);
+        // alpha[n+3:] = 0; alpha[:n-1] = 0; alpha[n-2] = 0.01 * val, with Python's index rules
+        // (a negative stop / index counts from the end)
+        int k1 = n - 1, k2 = n - 2;
+        if (k1 < 0) k1 = max(k1 + len, 0);
+        if (k2 < 0) k2 += len;
+        for (int t = tid; t < len; t += CTX_THREADS)
+          if (t >= n + 3 || t < k1) s_al[t] = 0.f;
+        __syncthreads();
+        if (tid == 0 && k2 >= 0 && k2 < len) s_al[k2] = 0.01f * val;
+        __syncthreads();
+      }
+      float s2 = 0.f;
+      for (int t = tid; t < len; t += CTX_THREADS) s2 += s_al[t];
+      s2 = block_sum(s2, s_red);
+      for (int t = tid; t < len; t += CTX_THREADS) {
+        const float a = s_al[t] / s2;
+        s_al[t] = a;
+        if (!done) p.alpha[(size_t)b * T + t] = a;
+      }
+      __syncthreads();
+    }
+    if (!done) {
+      const int row = cx->out_base + p.step_in_chunk;
+      for (int t = tid; t < T; t += CTX_THREADS) {
+        const float a = s_al[t];
+        p.a_prev[(size_t)b * T + t] = a;
+        cx->align[((size_t)b * cx->align_rows + row) * T + t] = a;
+      }
+    }
+    if (done) return;
+    block_context(p, b, len, s_al, s_acc, s_ctx);
+    if (p.forward_attn && p.trans_agent) {
+      float acc = 0.f;
+      for (int k = tid; k < ENC_DIM + QUERY_DIM; k += CTX_THREADS)
+        acc += p.ta_w[k] * (k < ENC_DIM ? s_ctx[k] : p.h_new[qidx(k - ENC_DIM, b, p.Bpad)]);
+      acc = block_sum(acc, s_red);
+      if (tid == 0) p.u[b] = sigmoidf_(acc + p.ta_b[0]);
+    }
+  }
+};
+
+// torch.nn.functional.softplus (beta 1, threshold 20)
+__device__ __forceinline__ float softplusf_(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+
+// GravesAttention.forward after the N_a network (Tacotron2/TTS/models.py:151-183): mixture
+// parameters from gbk = N_a(query) viewed [3][K], discretised weights
+//   alpha[t] = cdf[t+1] - cdf[t],  cdf[j] = sum_k g_k / (1 + sigmoid((mu_k - (j + 0.5)) / sig_k)),
+// exact zeros replaced by 1e-8, context.  One workgroup per utterance; positions beyond the
+// utterance's length get weight 0 (a batch-1 run of the unpadded text does not have them).
+constexpr int GRAVES_MAX_K = 16;
+struct GravesOp {
+  typedef AttnP P;
+  static __device__ __forceinline__ void run(const AttnP& p, int wg) {
+    RunCtx* cx = p.ctx;
+    const int done = cx->all_done;
+    const int T = p.T, b = wg, tid = threadIdx.x, K = p.graves_K;
+    const int len = p.len[b];
+    extern __shared__ float s_dyn[];
+    float* s_al = s_dyn;          // [T]
+    float* s_cdf = s_dyn + T;     // [T+1]
+    __shared__ float s_g[GRAVES_MAX_K], s_sig[GRAVES_MAX_K], s_mu[GRAVES_MAX_K];
+    __shared__ float4 s_acc[CTX_THREADS];
+    __shared__ __attribute__((aligned(16))) float s_ctx[ENC_DIM];
+    if (tid < K) {
+      s_g[tid] = p.gbk[qidx(tid, b, p.Bpad)];
+      s_sig[tid] = softplusf_(p.gbk[qidx(K + tid, b, p.Bpad)]) + 1e-5f;
+      s_mu[tid] = p.mu[b * K + tid] + softplusf_(p.gbk[qidx(2 * K + tid, b, p.Bpad)]);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      float m = -INFINITY, s = 0.f;
+      for (int k = 0; k < K; ++k) m = fmaxf(m, s_g[k]);
+      for (int k = 0; k < K; ++k) s += expf(s_g[k] - m);
+      for (int k = 0; k < K; ++k) s_g[k] = expf(s_g[k] - m) / s + 1e-5f;
+    }
+    __syncthreads();
+    for (int j = tid; j <= len; j += CTX_THREADS) {
+      float c = 0.f;
+      for (int k = 0; k < K; ++k) c += s_g[k] * (1.f / (1.f + sigmoidf_((s_mu[k] - ((float)j + 0.5f)) / s_sig[k])));
+      s_cdf[j] = c;
+    }
+    __syncthreads();
+    for (int t = tid; t < T; t += CTX_THREADS) {
+      float a = 0.f;
+      if (t < len) {
+        a = s_cdf[t + 1] - s_cdf[t];
+        if (a == 0.f) a = 1e-8f;
+      }
+      s_al[t] = a;
+    }
+    __syncthreads();
+    if (done) return;
+    if (tid < K) p.mu[b * K + tid] = s_mu[tid];
+    const int row = cx->out_base + p.step_in_chunk;
+    for (int t = tid; t < T; t += CTX_THREADS) {
+      p.a_prev[(size_t)b * T + t] = s_al[t];
+      cx->align[((size_t)b * cx->align_rows + row) * T + t] = s_al[t];
+    }
+    block_context(p, b, len, s_al, s_acc, s_ctx);
+  }
+};
+
 // processed_inputs P[b][t][d] = sum_c enc[b][t][c] * w_in[d][c]
 // (OriginalAttention.preprocess_inputs, once per utterance).
 __global__ __launch_bounds__(256) void inputs_proj_kernel(float* __restrict__ P, const float* __restrict__ enc,
@@ -746,6 +1008,30 @@ __global__ void init_x1_kernel(float* __restrict__ x1, const float* __restrict__
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < PRENET_DIM * Bpad) x1[qidx(i / Bpad, i % Bpad, Bpad)] = fmaxf(b1f[i / Bpad], 0.f);
 }
+// prenet layer 1 on an explicit memory frame (row-major [B,80]), any batch size: tiny, one thread per output
+__global__ void prenet1_explicit_kernel(float* __restrict__ x1, const float* __restrict__ mem,
+                                        const float* __restrict__ a1f, const float* __restrict__ b1f, int B,
+                                        int Bpad) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * PRENET_DIM) return;
+  const int b = i / PRENET_DIM, n = i % PRENET_DIM;
+  float acc = b1f[n];
+  for (int k = 0; k < MEL_DIM; ++k) acc += a1f[n * MEL_DIM + k] * mem[b * MEL_DIM + k];
+  x1[qidx(n, b, Bpad)] = fmaxf(acc, 0.f);
+}
+// initial state of the attention variants: forward-attention weights [1, 1e-7, 1e-7, ...] over the
+// utterance's own positions (OriginalAttention.init_forward_attn, Tacotron2/TTS/models.py:227-233),
+// transition probability 0.5, window index -1 (:222-225), Graves means 0 (:136)
+__global__ void init_variant_state_kernel(float* __restrict__ alpha, float* __restrict__ u, int32_t* __restrict__ win,
+                                          float* __restrict__ mu, const int32_t* __restrict__ len, int B, int T) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B * T) {
+    const int b = i / T, t = i % T;
+    alpha[i] = t >= len[b] ? 0.f : (t == 0 ? 1.f : 1e-7f);
+  }
+  if (i < B) u[i] = 0.5f, win[i] = -1;
+  if (i < B * GRAVES_MAX_K) mu[i] = 0.f;
+}
 // row-major [B][K] <-> quad-interleaved
 __global__ void to_quad_kernel(float* __restrict__ dst, const float* __restrict__ src, int B, int K, int Bpad) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -768,6 +1054,18 @@ struct ttsx_t2_decoder {
   float *w_proj, *b_proj;  // mel rows + composed rows, valid for proj_r
   int proj_r;
   float *inputs_w, *v_w, *v_b, *loc_conv_w, *loc_dense_w;
+  // optional attention variants
+  bool variant;      // any of windowing / forward attention: the one-workgroup-per-utterance tail
+  int windowing, forward_attn, forward_attn_mask, trans_agent, graves_K;
+  float *ta_w, *ta_b;
+  float *w_na1, *b_na1, *w_na2, *b_na2;  // packed GravesAttention.N_a layers
+  float *alpha, *u_fa, *mu, *n1, *gbk;   // workspace of the variants
+  int32_t* win_idx;
+  // one-shot settings of the next begin(): keep the recurrent state, first fed-back frame
+  bool keep_next, has_state;
+  float* mem0;       // [cap_B][80] copy of the caller's frame, valid when mem0_set
+  bool mem0_set;
+  int mem0_cap;
   // per-run workspace
   int B, T, Bpad, cap_B, cap_T, ws_gen;
   float *x1, *x2, *ctx, *h_a[2], *c_a, *h_d[2], *c_d, *q, *o, *a_prev, *a_cum, *energies, *P;
@@ -826,17 +1124,31 @@ void drop_graph(ttsx_t2_decoder* d) {
   d->graph = nullptr;
 }
 
+// Buffers sized by the (padded) batch alone - they hold the recurrent state, which
+// ttsx_t2_decoder_set_initial can carry into a run over a longer text - and buffers sized by batch x T.
+void free_len_workspace(ttsx_t2_decoder* d) {
+  float** bufs[] = {&d->a_prev, &d->a_cum, &d->energies, &d->P, &d->enc_ws, &d->alpha};
+  for (float** b : bufs) {
+    if (*b) (void)hipFree(*b);
+    *b = nullptr;
+  }
+  d->cap_T = 0;
+  drop_graph(d);
+}
+
 void free_workspace(ttsx_t2_decoder* d) {
+  free_len_workspace(d);
   float** bufs[] = {&d->x1, &d->x2, &d->ctx, &d->h_a[0], &d->h_a[1], &d->c_a, &d->h_d[0], &d->h_d[1], &d->c_d,
-                    &d->q,  &d->o,  &d->a_prev, &d->a_cum, &d->energies, &d->P, &d->g_a, &d->g_d, &d->enc_ws};
+                    &d->q,  &d->o,  &d->g_a, &d->g_d, &d->u_fa, &d->mu, &d->n1, &d->gbk};
   for (float** b : bufs) {
     if (*b) (void)hipFree(*b);
     *b = nullptr;
   }
   if (d->len_ws) (void)hipFree(d->len_ws);
   d->len_ws = nullptr;
-  d->cap_B = d->cap_T = 0;
-  drop_graph(d);
+  if (d->win_idx) (void)hipFree(d->win_idx);
+  d->win_idx = nullptr;
+  d->cap_B = 0;
 }
 
 int proj_rows(const ttsx_t2_decoder* d) { return d->odim + 16 + PRENET_DIM; }
@@ -845,35 +1157,46 @@ int ensure_workspace(ttsx_t2_decoder* d, int B, int T) {
   // column padding: 16 / 32 / multiples of 64 (a count of 3 column tiles would leave the LSTM launches
   // with one and a half waves of workgroups: slower than padding to 64)
   const int Bpad = B <= GEMV_MAX_B ? B : (B <= 32 ? round_up(B, 16) : round_up(B, 64));
-  if (d->cap_B == Bpad && d->cap_T >= T) {
-    d->Bpad = Bpad;
-    return TTSX_OK;
-  }
-  free_workspace(d);
   const size_t cb = Bpad, ct = T;
   int rc = 0;
-  rc |= dev_alloc(&d->x1, PRENET_DIM * cb);
-  rc |= dev_alloc(&d->x2, PRENET_DIM * cb);
-  rc |= dev_alloc(&d->ctx, ENC_DIM * cb);
-  for (int i = 0; i < 2; ++i) {
-    rc |= dev_alloc(&d->h_a[i], QUERY_DIM * cb);
-    rc |= dev_alloc(&d->h_d[i], DEC_DIM * cb);
+  if (d->cap_B != Bpad) {
+    free_workspace(d);
+    rc |= dev_alloc(&d->x1, PRENET_DIM * cb);
+    rc |= dev_alloc(&d->x2, PRENET_DIM * cb);
+    rc |= dev_alloc(&d->ctx, ENC_DIM * cb);
+    for (int i = 0; i < 2; ++i) {
+      rc |= dev_alloc(&d->h_a[i], QUERY_DIM * cb);
+      rc |= dev_alloc(&d->h_d[i], DEC_DIM * cb);
+    }
+    rc |= dev_alloc(&d->c_a, QUERY_DIM * cb);
+    rc |= dev_alloc(&d->c_d, DEC_DIM * cb);
+    rc |= dev_alloc(&d->g_a, 4 * QUERY_DIM * cb);
+    rc |= dev_alloc(&d->g_d, 4 * DEC_DIM * cb);
+    rc |= dev_alloc(&d->q, ATT_DIM * cb);
+    rc |= dev_alloc(&d->o, (size_t)round_up(proj_rows(d), 16) * cb);
+    rc |= dev_alloc(&d->len_ws, cb);
+    rc |= dev_alloc(&d->u_fa, cb);
+    rc |= dev_alloc(&d->win_idx, cb);
+    rc |= dev_alloc(&d->mu, cb * GRAVES_MAX_K);
+    rc |= dev_alloc(&d->n1, QUERY_DIM * cb);
+    rc |= dev_alloc(&d->gbk, (size_t)round_up(3 * GRAVES_MAX_K, 16) * cb);
+    if (rc) return TTSX_ERR_HIP;
+    d->cap_B = Bpad;
+    d->ws_gen += 1;
   }
-  rc |= dev_alloc(&d->c_a, QUERY_DIM * cb);
-  rc |= dev_alloc(&d->c_d, DEC_DIM * cb);
-  rc |= dev_alloc(&d->g_a, 4 * QUERY_DIM * cb);
-  rc |= dev_alloc(&d->g_d, 4 * DEC_DIM * cb);
-  rc |= dev_alloc(&d->q, ATT_DIM * cb);
-  rc |= dev_alloc(&d->o, (size_t)round_up(proj_rows(d), 16) * cb);
-  rc |= dev_alloc(&d->a_prev, cb * ct);
-  rc |= dev_alloc(&d->a_cum, cb * ct);
-  rc |= dev_alloc(&d->energies, cb * ct);
-  rc |= dev_alloc(&d->P, cb * ATT_DIM * ct);
-  rc |= dev_alloc(&d->enc_ws, cb * ENC_DIM * ct);
-  rc |= dev_alloc(&d->len_ws, cb);
-  if (rc) return TTSX_ERR_HIP;
-  d->cap_B = Bpad, d->cap_T = T, d->Bpad = Bpad;
-  d->ws_gen += 1;
+  if (d->cap_T < T) {
+    free_len_workspace(d);
+    rc |= dev_alloc(&d->a_prev, cb * ct);
+    rc |= dev_alloc(&d->a_cum, cb * ct);
+    rc |= dev_alloc(&d->energies, cb * ct);
+    rc |= dev_alloc(&d->P, cb * ATT_DIM * ct);
+    rc |= dev_alloc(&d->enc_ws, cb * ENC_DIM * ct);
+    rc |= dev_alloc(&d->alpha, cb * ct);
+    if (rc) return TTSX_ERR_HIP;
+    d->cap_T = T;
+    d->ws_gen += 1;
+  }
+  d->Bpad = Bpad;
   return TTSX_OK;
 }
 
@@ -982,6 +1305,13 @@ hipError_t set_context_lds_for(size_t bytes) {
 }
 hipError_t set_context_lds(size_t bytes) {
   hipError_t e;
+  // the one-workgroup-per-utterance variants keep up to three rows of T floats
+  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(dual_kernel<AttnPostOp, NoOp>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(3 * bytes))) != hipSuccess)
+    return e;
+  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(dual_kernel<GravesOp, NoOp>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * bytes + 64))) != hipSuccess)
+    return e;
   if ((e = set_context_lds_for<NoOp>(bytes)) != hipSuccess) return e;
   if ((e = set_context_lds_for<GemvOp<1, PK2, MODE_PARTIAL>>(bytes)) != hipSuccess) return e;
   return set_context_lds_for<GemvOp<2, PK2, MODE_PARTIAL>>(bytes);
@@ -1049,6 +1379,29 @@ int enqueue_step(ttsx_t2_decoder* d, int i, bool first, bool more, hipStream_t s
     rc = launch_gemm<MODE_LSTM, KG1 / GEMM_WAVES, PK1>(d, g, QUERY_DIM / 4, true, nullptr, st);
   }
   if (rc) return rc;
+  AttnP ap{};
+  ap.q = d->q, ap.P = d->P;
+  ap.loc_conv_t = d->loc_conv_w, ap.loc_dense_t = d->loc_dense_w, ap.v_w = d->v_w, ap.v_b = d->v_b;
+  ap.a_prev = d->a_prev, ap.a_cum = d->a_cum, ap.energies = d->energies, ap.ctx_out = d->ctx;
+  ap.enc = d->enc_ws, ap.len = d->len_ws, ap.T = T;
+  ap.ctx = d->rc, ap.step_in_chunk = i, ap.Bpad = Bpad, ap.norm = d->norm;
+  ap.windowing = d->windowing, ap.forward_attn = d->forward_attn, ap.forward_attn_mask = d->forward_attn_mask;
+  ap.trans_agent = d->trans_agent, ap.win_idx = d->win_idx, ap.alpha = d->alpha, ap.u = d->u_fa;
+  ap.ta_w = d->ta_w, ap.ta_b = d->ta_b, ap.h_new = g.parity ? d->h_a[0] : d->h_a[1];
+  ap.gbk = d->gbk, ap.mu = d->mu, ap.graves_K = d->graves_K;
+  if (d->graves_K > 0) {
+    // GravesAttention: gbk = N_a.2(relu(N_a.0(h_a))) as two row-block launches, then the mixture
+    g.Wp = d->w_na1, g.bias = d->b_na1, g.nseg = 1, g.KG = QUERY_DIM / 16, g.kg0 = 0, g.kg_stride = g.KG;
+    g.gates = nullptr;
+    g.seg[0] = Seg{{d->h_a[0], d->h_a[1]}, 2, QUERY_DIM / 16};
+    g.out[0] = d->n1, g.out[1] = nullptr, g.c = nullptr, g.relu = 1;
+    if ((rc = launch_gemm<MODE_LINEAR, 8, PK2>(d, g, QUERY_DIM / 16, false, nullptr, st))) return rc;
+    g.Wp = d->w_na2, g.bias = d->b_na2;
+    g.seg[0] = Seg{{d->n1, nullptr}, 0, QUERY_DIM / 16};
+    g.out[0] = d->gbk, g.relu = 0;
+    if ((rc = launch_gemm<MODE_LINEAR, 8, PK2>(d, g, ceil_div(3 * d->graves_K, 16), false, nullptr, st))) return rc;
+    if ((rc = launch_with_piece<GravesOp, PK2>(d, ap, B, sizeof(float) * (2 * T + 1), nullptr, st))) return rc;
+  } else {
   // query projection   (+ first third of the decoder partial)
   g.Wp = d->w_query, g.bias = d->b_query, g.nseg = 1, g.KG = QUERY_DIM / 16, g.kg0 = 0, g.kg_stride = g.KG;
   g.gates = nullptr;
@@ -1058,12 +1411,6 @@ int enqueue_step(ttsx_t2_decoder* d, int i, bool first, bool more, hipStream_t s
   pc.on = split;
   if ((rc = launch_gemm<MODE_LINEAR, 8, PK2>(d, g, ATT_DIM / 16, false, &pc, st))) return rc;
   // attention   (+ second and last third of the decoder partial)
-  AttnP ap{};
-  ap.q = d->q, ap.P = d->P;
-  ap.loc_conv_t = d->loc_conv_w, ap.loc_dense_t = d->loc_dense_w, ap.v_w = d->v_w, ap.v_b = d->v_b;
-  ap.a_prev = d->a_prev, ap.a_cum = d->a_cum, ap.energies = d->energies, ap.ctx_out = d->ctx;
-  ap.enc = d->enc_ws, ap.len = d->len_ws, ap.T = T;
-  ap.ctx = d->rc, ap.step_in_chunk = i, ap.Bpad = Bpad, ap.norm = d->norm;
   pc = pd.piece(1);
   pc.on = split;
   if (B >= 16) {
@@ -1076,7 +1423,10 @@ int enqueue_step(ttsx_t2_decoder* d, int i, bool first, bool more, hipStream_t s
   if (rc) return rc;
   pc = pd.piece(2);
   pc.on = split;
-  if (B >= 16) {
+  if (d->variant) {
+    // windowing / forward attention: the whole tail of an utterance in one workgroup
+    rc = launch_with_piece<AttnPostOp, PK2>(d, ap, B, sizeof(float) * 3 * T, nullptr, st);
+  } else if (B >= 16) {
     ap.gx = ENC_DIM / 128;
     rc = launch_with_piece<ContextOp<128>, PK2>(d, ap, ap.gx * B, sizeof(float) * T, &pc, st);
   } else {
@@ -1084,6 +1434,7 @@ int enqueue_step(ttsx_t2_decoder* d, int i, bool first, bool more, hipStream_t s
     rc = launch_with_piece<ContextOp<32>, PK2>(d, ap, ap.gx * B, sizeof(float) * T, &pc, st);
   }
   if (rc) return rc;
+  }
   // decoder LSTM: [ctx; h_a(new); h_d] (split: late columns [ctx] + the partial sums) + cell update
   //   (+ first third of the next attention partial)
   g.Wp = d->w_lstm2, g.bias = d->b_lstm2, g.kg0 = 0, g.kg_stride = KG2;
@@ -1178,7 +1529,9 @@ extern "C" int ttsx_t2_decoder_create(const ttsx_t2_decoder_weights* w, int r_in
   TTSX_LAUNCH_CHECK();
   rc |= pack_layer(&d->w_lstm2, &d->b_lstm2, w_ih2, ENC_DIM + QUERY_DIM, w->dec_rnn_w_hh, DEC_DIM,
                    w->dec_rnn_b_ih, w->dec_rnn_b_hh, 4 * DEC_DIM, DEC_DIM, st);
-  rc |= pack_layer(&d->w_query, &d->b_query, w->query_w, QUERY_DIM, nullptr, 0, nullptr, nullptr, ATT_DIM, 0, st);
+  // (a decoder with GravesAttention has no query / inputs / v / location tensors)
+  if (w->query_w)
+    rc |= pack_layer(&d->w_query, &d->b_query, w->query_w, QUERY_DIM, nullptr, 0, nullptr, nullptr, ATT_DIM, 0, st);
   if (rc) return TTSX_ERR_HIP;
   // prenet: fold BatchNorm, keep layer 1 in source layout for the composed projection rows
   float *a2f = nullptr, *b2f = nullptr;
@@ -1198,15 +1551,22 @@ extern "C" int ttsx_t2_decoder_create(const ttsx_t2_decoder_weights* w, int r_in
   rc |= copy_dev(&d->proj_b_src, w->proj_b, d->odim, st);
   rc |= copy_dev(&d->stop_w_src, w->stop_w, DEC_DIM + d->odim, st);
   rc |= copy_dev(&d->stop_b_src, w->stop_b, 1, st);
-  rc |= copy_dev(&d->inputs_w, w->inputs_w, ATT_DIM * ENC_DIM, st);
-  rc |= copy_dev(&d->v_w, w->v_w, ATT_DIM, st);
-  rc |= copy_dev(&d->v_b, w->v_b, 1, st);
+  if (w->inputs_w) rc |= copy_dev(&d->inputs_w, w->inputs_w, ATT_DIM * ENC_DIM, st);
+  if (w->v_w) rc |= copy_dev(&d->v_w, w->v_w, ATT_DIM, st);
+  if (w->v_b) rc |= copy_dev(&d->v_b, w->v_b, 1, st);
   rc |= dev_alloc(&d->loc_conv_w, LOC_F * 2 * LOC_K);
   rc |= dev_alloc(&d->loc_dense_w, ATT_DIM * LOC_F);
   if (rc) return TTSX_ERR_HIP;
-  transpose_loc_kernel<<<ceil_div(ATT_DIM * LOC_F, 256), 256, 0, st>>>(d->loc_conv_w, d->loc_dense_w, w->loc_conv_w,
-                                                                      w->loc_dense_w);
-  TTSX_LAUNCH_CHECK();
+  if (w->loc_conv_w && w->loc_dense_w) {
+    transpose_loc_kernel<<<ceil_div(ATT_DIM * LOC_F, 256), 256, 0, st>>>(d->loc_conv_w, d->loc_dense_w,
+                                                                        w->loc_conv_w, w->loc_dense_w);
+    TTSX_LAUNCH_CHECK();
+  } else {
+    // location_attn = false (OriginalAttention.get_attention, Tacotron2/TTS/models.py:269-273): the
+    // location term is absent, which all-zero location weights reproduce exactly
+    TTSX_HIP(hipMemsetAsync(d->loc_conv_w, 0, sizeof(float) * LOC_F * 2 * LOC_K, st));
+    TTSX_HIP(hipMemsetAsync(d->loc_dense_w, 0, sizeof(float) * ATT_DIM * LOC_F, st));
+  }
   TTSX_HIP(hipMalloc(reinterpret_cast<void**>(&d->rc), sizeof(RunCtx)));
   TTSX_HIP(hipMemsetAsync(d->rc, 0, sizeof(RunCtx), st));
   TTSX_HIP(hipHostMalloc(reinterpret_cast<void**>(&d->rc_host), sizeof(RunCtx), hipHostMallocDefault));
@@ -1226,7 +1586,8 @@ extern "C" int ttsx_t2_decoder_destroy(ttsx_t2_decoder* d) {
   free_workspace(d);
   float* bufs[] = {d->w_lstm1, d->b_lstm1, d->w_lstm2, d->b_lstm2, d->w_query, d->b_query,
                    d->w_pre2,  d->b_pre2,  d->w_proj,  d->b_proj,  d->proj_w_src, d->proj_b_src, d->stop_w_src,
-                   d->stop_b_src, d->a1f, d->b1f, d->inputs_w, d->v_w, d->v_b, d->loc_conv_w, d->loc_dense_w};
+                   d->stop_b_src, d->a1f, d->b1f, d->inputs_w, d->v_w, d->v_b, d->loc_conv_w, d->loc_dense_w,
+                   d->ta_w, d->ta_b, d->w_na1, d->b_na1, d->w_na2, d->b_na2, d->mem0};
   for (float* b : bufs)
     if (b) (void)hipFree(b);
   if (d->cap_stream) (void)hipStreamDestroy(d->cap_stream);
@@ -1234,6 +1595,65 @@ extern "C" int ttsx_t2_decoder_destroy(ttsx_t2_decoder* d) {
   if (d->rc_host) (void)hipHostFree(d->rc_host);
   if (d->host_flag) (void)hipHostFree(d->host_flag);
   delete d;
+  return TTSX_OK;
+}
+
+extern "C" int ttsx_t2_decoder_set_attention(ttsx_t2_decoder* d, const ttsx_t2_attention_options* o, void* stream) {
+  TTSX_ARG(d && o, "ttsx_t2_decoder_set_attention: null argument");
+  TTSX_ARG(!o->trans_agent || (o->forward_attn && o->ta_w && o->ta_b),
+           "ttsx_t2_decoder_set_attention: the transition agent needs forward attention and its weights");
+  TTSX_ARG(o->graves_K >= 0 && o->graves_K <= GRAVES_MAX_K, "ttsx_t2_decoder_set_attention: graves_K=%d outside 0..%d",
+           o->graves_K, GRAVES_MAX_K);
+  TTSX_ARG(o->graves_K == 0 || (o->graves_w1 && o->graves_b1 && o->graves_w2 && o->graves_b2),
+           "ttsx_t2_decoder_set_attention: GravesAttention weights missing");
+  TTSX_ARG(o->graves_K == 0 || !(o->windowing || o->forward_attn),
+           "ttsx_t2_decoder_set_attention: windowing / forward attention belong to the original attention");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  d->windowing = o->windowing != 0, d->forward_attn = o->forward_attn != 0;
+  d->forward_attn_mask = o->forward_attn_mask != 0, d->trans_agent = o->trans_agent != 0;
+  d->graves_K = o->graves_K;
+  d->variant = d->windowing || d->forward_attn;
+  int rc = 0;
+  if (d->trans_agent) {
+    if (d->ta_w) (void)hipFree(d->ta_w), (void)hipFree(d->ta_b);
+    d->ta_w = d->ta_b = nullptr;
+    rc |= copy_dev(&d->ta_w, o->ta_w, ENC_DIM + QUERY_DIM, st);
+    rc |= copy_dev(&d->ta_b, o->ta_b, 1, st);
+  }
+  if (d->graves_K > 0) {
+    float** old[] = {&d->w_na1, &d->b_na1, &d->w_na2, &d->b_na2};  // sizes depend on K: pack afresh
+    for (float** b : old) {
+      if (*b) (void)hipFree(*b);
+      *b = nullptr;
+    }
+    rc |= pack_layer(&d->w_na1, &d->b_na1, o->graves_w1, QUERY_DIM, nullptr, 0, o->graves_b1, nullptr, QUERY_DIM, 0, st);
+    rc |= pack_layer(&d->w_na2, &d->b_na2, o->graves_w2, QUERY_DIM, nullptr, 0, o->graves_b2, nullptr,
+                     3 * d->graves_K, 0, st);
+  }
+  if (rc) return TTSX_ERR_HIP;
+  TTSX_HIP(hipStreamSynchronize(st));
+  drop_graph(d);
+  d->g_gen = -1;
+  return TTSX_OK;
+}
+
+extern "C" int ttsx_t2_decoder_set_initial(ttsx_t2_decoder* d, int keep_states, const float* memory, int B,
+                                           void* stream) {
+  TTSX_ARG(d, "ttsx_t2_decoder_set_initial: null handle");
+  TTSX_ARG(B >= 1 && B <= 4096, "ttsx_t2_decoder_set_initial: B=%d", B);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  d->keep_next = keep_states != 0;
+  d->mem0_set = false;
+  if (memory) {
+    if (d->mem0_cap < B) {
+      if (d->mem0) (void)hipFree(d->mem0);
+      d->mem0 = nullptr;
+      if (dev_alloc(&d->mem0, (size_t)B * MEL_DIM)) return TTSX_ERR_HIP;
+      d->mem0_cap = B;
+    }
+    TTSX_HIP(hipMemcpyAsync(d->mem0, memory, sizeof(float) * (size_t)B * MEL_DIM, hipMemcpyDeviceToDevice, st));
+    d->mem0_set = true;
+  }
   return TTSX_OK;
 }
 
@@ -1245,42 +1665,78 @@ extern "C" int ttsx_t2_decoder_begin(ttsx_t2_decoder* d, const float* enc, const
   hipStream_t st = static_cast<hipStream_t>(stream);
   int rc = ensure_workspace(d, B, T);
   if (rc) return rc;
+  const bool keep = d->keep_next && d->has_state && d->B == B;
+  if (d->keep_next && !keep) {
+    d->keep_next = false, d->mem0_set = false;
+    ttsx_set_error("ttsx_t2_decoder_begin: no recurrent state of a %d-utterance run to keep", B);
+    return TTSX_ERR_STATE;
+  }
+  const bool graves = d->graves_K > 0;
+  if (!graves && !(d->w_query && d->inputs_w && d->v_w && d->v_b)) {
+    ttsx_set_error("ttsx_t2_decoder_begin: attention weights missing (query / inputs / v)");
+    return TTSX_ERR_ARG;
+  }
+  TTSX_ARG(!(d->variant || graves) || T <= 12000,
+           "ttsx_t2_decoder_begin: encoder length %d exceeds the LDS budget of the attention variants", T);
   d->B = B, d->T = T;
   {
     // early/late LSTM split: pays where the launches are latency-bound (GEMV regime; measured slower
     // on the MFMA path, where the pieces cost a full activation pass each); TTSX_SPLIT=0 turns it off
     const char* e = getenv("TTSX_SPLIT");
-    d->split = B <= GEMV_MAX_B && !(e && e[0] == '0');
+    d->split = B <= GEMV_MAX_B && !(e && e[0] == '0') && !d->variant && !graves;
   }
   d->parity0 = 0;
   const size_t cb = d->Bpad;
   TTSX_HIP(hipMemsetAsync(d->x2, 0, sizeof(float) * PRENET_DIM * cb, st));
-  TTSX_HIP(hipMemsetAsync(d->ctx, 0, sizeof(float) * ENC_DIM * cb, st));
-  for (int i = 0; i < 2; ++i) {
-    TTSX_HIP(hipMemsetAsync(d->h_a[i], 0, sizeof(float) * QUERY_DIM * cb, st));
-    TTSX_HIP(hipMemsetAsync(d->h_d[i], 0, sizeof(float) * DEC_DIM * cb, st));
+  if (keep) {
+    // Decoder._init_states(keep_states=True), Tacotron2/TTS/models.py:536-552: the LSTM states and the
+    // context stay; the current hidden states move to the buffers a run starts from
+    if (d->steps_done & 1) {
+      TTSX_HIP(hipMemcpyAsync(d->h_a[0], d->h_a[1], sizeof(float) * QUERY_DIM * cb, hipMemcpyDeviceToDevice, st));
+      TTSX_HIP(hipMemcpyAsync(d->h_d[0], d->h_d[1], sizeof(float) * DEC_DIM * cb, hipMemcpyDeviceToDevice, st));
+    }
+  } else {
+    TTSX_HIP(hipMemsetAsync(d->ctx, 0, sizeof(float) * ENC_DIM * cb, st));
+    for (int i = 0; i < 2; ++i) {
+      TTSX_HIP(hipMemsetAsync(d->h_a[i], 0, sizeof(float) * QUERY_DIM * cb, st));
+      TTSX_HIP(hipMemsetAsync(d->h_d[i], 0, sizeof(float) * DEC_DIM * cb, st));
+    }
+    TTSX_HIP(hipMemsetAsync(d->c_a, 0, sizeof(float) * QUERY_DIM * cb, st));
+    TTSX_HIP(hipMemsetAsync(d->c_d, 0, sizeof(float) * DEC_DIM * cb, st));
   }
-  TTSX_HIP(hipMemsetAsync(d->c_a, 0, sizeof(float) * QUERY_DIM * cb, st));
-  TTSX_HIP(hipMemsetAsync(d->c_d, 0, sizeof(float) * DEC_DIM * cb, st));
   TTSX_HIP(hipMemsetAsync(d->q, 0, sizeof(float) * ATT_DIM * cb, st));
   TTSX_HIP(hipMemsetAsync(d->o, 0, sizeof(float) * (size_t)round_up(proj_rows(d), 16) * cb, st));
+  TTSX_HIP(hipMemsetAsync(d->n1, 0, sizeof(float) * QUERY_DIM * cb, st));
+  TTSX_HIP(hipMemsetAsync(d->gbk, 0, sizeof(float) * (size_t)round_up(3 * GRAVES_MAX_K, 16) * cb, st));
   TTSX_HIP(hipMemsetAsync(d->a_prev, 0, sizeof(float) * (size_t)B * T, st));
   TTSX_HIP(hipMemsetAsync(d->a_cum, 0, sizeof(float) * (size_t)B * T, st));
-  init_x1_kernel<<<ceil_div(PRENET_DIM * (int)cb, 256), 256, 0, st>>>(d->x1, d->b1f, (int)cb);
+  if (d->mem0_set) {
+    // first step fed a given frame instead of the all-zero go frame
+    prenet1_explicit_kernel<<<ceil_div(B * PRENET_DIM, 256), 256, 0, st>>>(d->x1, d->mem0, d->a1f, d->b1f, B, (int)cb);
+  } else if (!keep) {
+    init_x1_kernel<<<ceil_div(PRENET_DIM * (int)cb, 256), 256, 0, st>>>(d->x1, d->b1f, (int)cb);
+  }  // (keep without a frame: x1 already holds layer 1 of the last emitted frame)
   TTSX_LAUNCH_CHECK();
-  if (sizeof(float) * T > 48 * 1024) {
+  d->keep_next = false, d->mem0_set = false;
+  if (3 * sizeof(float) * T > 48 * 1024) {
     TTSX_HIP(set_context_lds(sizeof(float) * T));
   }
   TTSX_HIP(hipMemcpyAsync(d->enc_ws, enc, sizeof(float) * (size_t)B * T * ENC_DIM, hipMemcpyDeviceToDevice, st));
   fill_len_kernel<<<ceil_div(B, 256), 256, 0, st>>>(d->len_ws, enc_len, B, T);
   TTSX_LAUNCH_CHECK();
-  inputs_proj_kernel<<<dim3(ceil_div(T, 16), B), 256, 0, st>>>(d->P, d->enc_ws, d->inputs_w, T);
+  init_variant_state_kernel<<<ceil_div(std::max(B * T, B * GRAVES_MAX_K), 256), 256, 0, st>>>(
+      d->alpha, d->u_fa, d->win_idx, d->mu, d->len_ws, B, T);
   TTSX_LAUNCH_CHECK();
+  if (!graves) {
+    inputs_proj_kernel<<<dim3(ceil_div(T, 16), B), 256, 0, st>>>(d->P, d->enc_ws, d->inputs_w, T);
+    TTSX_LAUNCH_CHECK();
+  }
   RunCtx* h = d->rc_host;
   memset(h, 0, sizeof(*h));
   h->B = B, h->T = T, h->r = d->proj_r, h->threshold = 2.f;
   d->steps_done = 0;
   d->begun = true;
+  d->has_state = true;
   return push_ctx(d, st);
 }
 
@@ -1330,20 +1786,6 @@ extern "C" int ttsx_t2_decoder_read_state(ttsx_t2_decoder* d, float* h_a, float*
   if (a_cum) TTSX_HIP(hipMemcpyAsync(a_cum, d->a_cum, sizeof(float) * (size_t)B * d->T, hipMemcpyDeviceToDevice, st));
   return TTSX_OK;
 }
-
-namespace {
-// prenet layer 1 on an explicit memory frame (row-major [B,80]), any batch size: tiny, one thread per output
-__global__ void prenet1_explicit_kernel(float* __restrict__ x1, const float* __restrict__ mem,
-                                        const float* __restrict__ a1f, const float* __restrict__ b1f, int B,
-                                        int Bpad) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= B * PRENET_DIM) return;
-  const int b = i / PRENET_DIM, n = i % PRENET_DIM;
-  float acc = b1f[n];
-  for (int k = 0; k < MEL_DIM; ++k) acc += a1f[n * MEL_DIM + k] * mem[b * MEL_DIM + k];
-  x1[qidx(n, b, Bpad)] = fmaxf(acc, 0.f);
-}
-}  // namespace
 
 extern "C" int ttsx_t2_decoder_step(ttsx_t2_decoder* d, const float* memory, int r, float* frames, float* align,
                                     float* stop, void* stream) {
@@ -1519,7 +1961,14 @@ extern "C" int ttsx_encoder_lstm_destroy(ttsx_encoder_lstm* e) {
 
 extern "C" int ttsx_encoder_lstm_run(ttsx_encoder_lstm* e, const float* x, const int32_t* lengths, int B, int T,
                                      float* out, void* stream) {
+  return ttsx_encoder_lstm_run_stateful(e, x, lengths, B, T, out, nullptr, nullptr, stream);
+}
+
+extern "C" int ttsx_encoder_lstm_run_stateful(ttsx_encoder_lstm* e, const float* x, const int32_t* lengths, int B,
+                                              int T, float* out, float* h_state, float* c_state, void* stream) {
   TTSX_ARG(e && x && out, "ttsx_encoder_lstm_run: null argument");
+  TTSX_ARG((h_state == nullptr) == (c_state == nullptr), "ttsx_encoder_lstm_run_stateful: give both states or neither");
+  TTSX_ARG(!h_state || !lengths, "ttsx_encoder_lstm_run_stateful: a carried state needs full-length utterances");
   TTSX_ARG(B >= 1 && B <= 4096 && T >= 1, "ttsx_encoder_lstm_run: bad shape B=%d T=%d", B, T);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int Bc = B <= GEMV_MAX_B ? B : (B <= 32 ? round_up(B, 16) : round_up(B, 64));
@@ -1547,6 +1996,11 @@ extern "C" int ttsx_encoder_lstm_run(ttsx_encoder_lstm* e, const float* x, const
   for (int d = 0; d < 2; ++d) {
     TTSX_HIP(hipMemsetAsync(e->h[d][0], 0, sizeof(float) * ENC_H * Bc, st));
     TTSX_HIP(hipMemsetAsync(e->c[d], 0, sizeof(float) * ENC_H * Bc, st));
+    if (h_state) {
+      to_quad_kernel<<<ceil_div(B * ENC_H, 256), 256, 0, st>>>(e->h[d][0], h_state + (size_t)d * B * ENC_H, B, ENC_H, Bc);
+      to_quad_kernel<<<ceil_div(B * ENC_H, 256), 256, 0, st>>>(e->c[d], c_state + (size_t)d * B * ENC_H, B, ENC_H, Bc);
+      TTSX_LAUNCH_CHECK();
+    }
     GemmP g{};
     g.Wp = e->w_ih[d], g.nseg = 1, g.KG = ENC_IN / 16, g.Bpad = Ct, g.kg0 = 0, g.kg_stride = ENC_IN / 16;
     g.rb0 = 0, g.nrb = ENC_H / 4, g.seg[0] = Seg{{e->xq, nullptr}, 0, ENC_IN / 16};
@@ -1578,5 +2032,38 @@ extern "C" int ttsx_encoder_lstm_run(ttsx_encoder_lstm* e, const float* x, const
     }
     TTSX_LAUNCH_CHECK();
   }
+  if (h_state) {
+    // step s writes the buffer of parity (s & 1) ^ 1, so the state after T steps sits in h[T & 1]
+    for (int d = 0; d < 2; ++d) {
+      from_quad_kernel<<<ceil_div(B * ENC_H, 256), 256, 0, st>>>(h_state + (size_t)d * B * ENC_H, e->h[d][T & 1], B, ENC_H, Bc);
+      from_quad_kernel<<<ceil_div(B * ENC_H, 256), 256, 0, st>>>(c_state + (size_t)d * B * ENC_H, e->c[d], B, ENC_H, Bc);
+    }
+    TTSX_LAUNCH_CHECK();
+  }
+  return TTSX_OK;
+}
+
+// Tacotron2._add_speaker_embedding (Tacotron2/TTS/models.py:838-849): the speaker's embedding row is
+// added to every encoder position.  Ids outside the table are clamped (the caller validates them).
+namespace {
+__global__ void add_speaker_kernel(float4* __restrict__ enc, const float4* __restrict__ table,
+                                   const int32_t* __restrict__ ids, int n_speakers, int B, int T) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)B * T * (ENC_DIM / 4)) return;
+  const int b = (int)(i / ((size_t)T * (ENC_DIM / 4))), c4 = (int)(i % (ENC_DIM / 4));
+  const int id = min(max(ids[b], 0), n_speakers - 1);
+  const float4 e = enc[i], s = table[(size_t)id * (ENC_DIM / 4) + c4];
+  enc[i] = make_float4(e.x + s.x, e.y + s.y, e.z + s.z, e.w + s.w);
+}
+}  // namespace
+
+extern "C" int ttsx_add_speaker_embedding(float* enc, const float* table, const int32_t* speaker_ids, int n_speakers,
+                                          int B, int T, void* stream) {
+  TTSX_ARG(enc && table && speaker_ids, "ttsx_add_speaker_embedding: null argument");
+  TTSX_ARG(n_speakers >= 1 && B >= 1 && T >= 1, "ttsx_add_speaker_embedding: bad shape");
+  const size_t n = (size_t)B * T * (ENC_DIM / 4);
+  add_speaker_kernel<<<(unsigned)((n + 255) / 256), 256, 0, static_cast<hipStream_t>(stream)>>>(
+      reinterpret_cast<float4*>(enc), reinterpret_cast<const float4*>(table), speaker_ids, n_speakers, B, T);
+  TTSX_LAUNCH_CHECK();
   return TTSX_OK;
 }

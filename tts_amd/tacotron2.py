@@ -8,6 +8,12 @@ loop, attention, postnet and the encoder (3 conv blocks, BiLSTM) run in
 hand-written HIP kernels through the C ABI; only the embedding lookup is a
 stock PyTorch-ROCm op.
 
+The reference's optional variants are available too (all off in the repo's
+config.json): attention windowing, forward attention with transition agent and
+masking, attention without location features, Graves attention
+(`attn_type="graves"`), speaker embeddings (`num_speakers > 1`) and
+`inference_truncated`.  The bidirectional decoder is training-only and absent.
+
 Extensions the reference does not have (its `inference` is batch-1 only,
 models.py:661): `inference_batch` decodes B utterances at once with
 per-utterance stop handling and optional length masking.
@@ -48,25 +54,33 @@ class Tacotron2:
                  attn_type="original", attn_win=False, attn_norm="softmax", prenet_type="original",
                  prenet_dropout=True, forward_attn=False, trans_agent=False, forward_attn_mask=False,
                  location_attn=True, attn_K=5, separate_stopnet=True, bidirectional_decoder=False):
-        if attn_type != "original":
-            if attn_type == "graves":
-                raise NotImplementedError("graves attention is outside the accelerated path")
+        if attn_type not in ("original", "graves"):
             raise RuntimeError(" [!] Given Attention Type '{attn_type}' is not exist.")
         if attn_norm not in ("softmax", "sigmoid"):
             raise ValueError("Unknown value for attention norm type")
         if prenet_type not in ("original", "bn"):
             raise ValueError("unknown prenet_type %r" % (prenet_type,))
-        for flag, name in ((attn_win, "windowing"), (forward_attn, "use_forward_attn"),
-                           (trans_agent, "transition_agent"), (bidirectional_decoder, "bidirectional_decoder"),
-                           (not location_attn, "location_attn=false"), (num_speakers > 1, "speaker embeddings")):
-            if flag:
-                raise NotImplementedError("%s is outside the accelerated path" % name)
+        if bidirectional_decoder:
+            # the backward decoder only runs in Tacotron2.forward (training), models.py:797-799
+            raise NotImplementedError("bidirectional_decoder is training-only; the accelerated path is inference")
         if postnet_output_dim != 80 or decoder_output_dim != 80:
             raise NotImplementedError("only 80 mel bins are supported")
+        if attn_type == "graves" and not 1 <= attn_K <= 16:
+            raise ValueError("attn_K must be in 1..16")
         self.num_chars = num_chars
+        self.num_speakers = num_speakers
         self.n_frames_per_step = r
         self.attn_norm = attn_norm
         self.prenet_type = prenet_type
+        self.attn_type = attn_type
+        self.attn_K = attn_K
+        self.attn_win = bool(attn_win)
+        self.forward_attn = bool(forward_attn)
+        self.trans_agent = bool(trans_agent)
+        self.forward_attn_mask = bool(forward_attn_mask)
+        self.location_attn = bool(location_attn)
+        self._rnn_state = None          # encoder BiLSTM state carried by inference_truncated
+        self._memory_truncated = None   # frame fed to the first step of the next truncated call
         self.decoder = _Decoder(r)
         self.device = torch.device("cpu")
         self.training = False
@@ -85,6 +99,16 @@ class Tacotron2:
             sd[k] = v
         need = ["embedding.weight", "decoder.attention_rnn.weight_ih", "decoder.decoder_rnn.weight_ih",
                 "decoder.linear_projection.linear_layer.weight", "postnet.convolutions.4.net.0.weight"]
+        if self.attn_type == "graves":
+            need += ["decoder.attention.N_a.0.weight", "decoder.attention.N_a.2.weight"]
+        else:
+            need += ["decoder.attention.query_layer.linear_layer.weight", "decoder.attention.v.linear_layer.weight"]
+            if self.location_attn:
+                need.append("decoder.attention.location_layer.location_conv.weight")
+            if self.forward_attn and self.trans_agent:
+                need.append("decoder.attention.ta.weight")
+        if self.num_speakers > 1:
+            need.append("speaker_embedding.weight")
         missing = [k for k in need if k not in sd]
         if missing:
             raise RuntimeError("Missing key(s) in state_dict: %s" % ", ".join(missing))
@@ -157,13 +181,16 @@ class Tacotron2:
             w.prenet_bn_mean[i] = sd[p + "bn.running_mean"].data_ptr() if bn else None
             w.prenet_bn_var[i] = sd[p + "bn.running_var"].data_ptr() if bn else None
         g = lambda k: sd["decoder." + k].data_ptr()
+        graves = self.attn_type == "graves"
         w.attn_rnn_w_ih, w.attn_rnn_w_hh = g("attention_rnn.weight_ih"), g("attention_rnn.weight_hh")
         w.attn_rnn_b_ih, w.attn_rnn_b_hh = g("attention_rnn.bias_ih"), g("attention_rnn.bias_hh")
-        w.query_w = g("attention.query_layer.linear_layer.weight")
-        w.inputs_w = g("attention.inputs_layer.linear_layer.weight")
-        w.v_w, w.v_b = g("attention.v.linear_layer.weight"), g("attention.v.linear_layer.bias")
-        w.loc_conv_w = g("attention.location_layer.location_conv.weight")
-        w.loc_dense_w = g("attention.location_layer.location_dense.linear_layer.weight")
+        if not graves:
+            w.query_w = g("attention.query_layer.linear_layer.weight")
+            w.inputs_w = g("attention.inputs_layer.linear_layer.weight")
+            w.v_w, w.v_b = g("attention.v.linear_layer.weight"), g("attention.v.linear_layer.bias")
+            if self.location_attn:
+                w.loc_conv_w = g("attention.location_layer.location_conv.weight")
+                w.loc_dense_w = g("attention.location_layer.location_dense.linear_layer.weight")
         w.dec_rnn_w_ih, w.dec_rnn_w_hh = g("decoder_rnn.weight_ih"), g("decoder_rnn.weight_hh")
         w.dec_rnn_b_ih, w.dec_rnn_b_hh = g("decoder_rnn.bias_ih"), g("decoder_rnn.bias_hh")
         w.proj_w, w.proj_b = g("linear_projection.linear_layer.weight"), g("linear_projection.linear_layer.bias")
@@ -175,6 +202,19 @@ class Tacotron2:
                                                   _lib.current_stream(), ctypes.byref(handle)),
                        "ttsx_t2_decoder_create")
             self._dec_handle = handle
+            if graves or self.attn_win or self.forward_attn:
+                o = _lib.T2AttentionOptions()
+                o.windowing, o.forward_attn = int(self.attn_win), int(self.forward_attn)
+                o.forward_attn_mask = int(self.forward_attn and self.forward_attn_mask)
+                o.trans_agent = int(self.forward_attn and self.trans_agent)
+                if o.trans_agent:
+                    o.ta_w, o.ta_b = g("attention.ta.weight"), g("attention.ta.bias")
+                if graves:
+                    o.graves_K = self.attn_K
+                    o.graves_w1, o.graves_b1 = g("attention.N_a.0.weight"), g("attention.N_a.0.bias")
+                    o.graves_w2, o.graves_b2 = g("attention.N_a.2.weight"), g("attention.N_a.2.bias")
+                _lib.check(lib.ttsx_t2_decoder_set_attention(handle, ctypes.byref(o), _lib.current_stream()),
+                           "ttsx_t2_decoder_set_attention")
             pw = _lib.PostnetWeights()
             for i in range(5):
                 p = "postnet.convolutions.%d.net." % i
@@ -211,11 +251,14 @@ class Tacotron2:
 
     # ---- forward pieces ----------------------------------------------------
     @torch.no_grad()
-    def encode(self, text, text_lengths=None):
+    def encode(self, text, text_lengths=None, speaker_ids=None, rnn_state=None):
         """Embedding + Encoder.inference (Tacotron2/TTS/models.py:803-804, 449-454).  The three
         conv blocks (position-major, so the embedding output is consumed as it is) and the BiLSTM
         run in HIP kernels; the embedding lookup is a stock op.  With `text_lengths` every
-        utterance is encoded as its unpadded batch-1 run would be."""
+        utterance is encoded as its unpadded batch-1 run would be.  `speaker_ids` adds the
+        speaker embedding (_add_speaker_embedding, :838-849); `rnn_state` = (h, c), each
+        [2,B,256], is the BiLSTM state to start from and is overwritten with the final one
+        (Encoder.inference_truncated, :456-464)."""
         lib = _lib.load()
         sd = self._sd
         x = F.embedding(text, sd["embedding.weight"]).contiguous()          # [B,T,512]
@@ -228,14 +271,31 @@ class Tacotron2:
         with torch.cuda.device(x.device):
             _lib.check(lib.ttsx_encoder_convs_run(self._enc_handle, _lib.ptr(x), _lib.ptr(lens), B, T, _lib.ptr(y),
                                                   _lib.current_stream()), "ttsx_encoder_convs_run")
-            _lib.check(lib.ttsx_encoder_lstm_run(self._lstm_handle, _lib.ptr(y), _lib.ptr(lens), B, T, _lib.ptr(out),
-                                                 _lib.current_stream()), "ttsx_encoder_lstm_run")
+            if rnn_state is None:
+                _lib.check(lib.ttsx_encoder_lstm_run(self._lstm_handle, _lib.ptr(y), _lib.ptr(lens), B, T,
+                                                     _lib.ptr(out), _lib.current_stream()), "ttsx_encoder_lstm_run")
+            else:
+                _lib.check(lib.ttsx_encoder_lstm_run_stateful(self._lstm_handle, _lib.ptr(y), _lib.ptr(lens), B, T,
+                                                              _lib.ptr(out), _lib.ptr(rnn_state[0]),
+                                                              _lib.ptr(rnn_state[1]), _lib.current_stream()),
+                           "ttsx_encoder_lstm_run_stateful")
+            if self.num_speakers > 1:
+                if speaker_ids is None:
+                    raise RuntimeError(" [!] Model has speaker embedding layer but speaker_id is not provided")
+                ids = torch.as_tensor(speaker_ids).reshape(-1).cpu()
+                if ids.numel() != B or int(ids.min()) < 0 or int(ids.max()) >= self.num_speakers:
+                    raise IndexError("speaker_ids must hold one id in [0, %d) per utterance" % self.num_speakers)
+                ids = ids.to(device=x.device, dtype=torch.int32).contiguous()
+                _lib.check(lib.ttsx_add_speaker_embedding(_lib.ptr(out), _lib.ptr(sd["speaker_embedding.weight"]),
+                                                          _lib.ptr(ids), self.num_speakers, B, T,
+                                                          _lib.current_stream()), "ttsx_add_speaker_embedding")
         return out
 
     @torch.no_grad()
-    def decode(self, enc, enc_len=None, fixed_steps=None):
+    def decode(self, enc, enc_len=None, fixed_steps=None, keep_states=False, memory=None):
         """Greedy decoder loop on the GPU.  Returns (mel [B,F,80], align [B,S,T], stop [B,S],
-        n_steps [B] int32, steps_run)."""
+        n_steps [B] int32, steps_run).  `keep_states` / `memory` [B,80]: start from the recurrent
+        state the previous call left and feed `memory` to the first step (inference_truncated)."""
         lib = _lib.load()
         B, T, _ = enc.shape
         r = self.decoder.r
@@ -249,6 +309,12 @@ class Tacotron2:
         if enc_len is not None:
             enc_len = enc_len.to(device=dev, dtype=torch.int32).contiguous()
         with torch.cuda.device(dev):
+            if keep_states or memory is not None:
+                if memory is not None:
+                    memory = memory.to(device=dev, dtype=torch.float32).contiguous()
+                _lib.check(lib.ttsx_t2_decoder_set_initial(self._dec_handle, 1 if keep_states else 0,
+                                                           _lib.ptr(memory), B, _lib.current_stream()),
+                           "ttsx_t2_decoder_set_initial")
             _lib.check(lib.ttsx_t2_decoder_run(self._dec_handle, _lib.ptr(enc), _lib.ptr(enc_len), B, T, r,
                                                max_steps, self.decoder.stop_threshold,
                                                1 if fixed_steps else 0, _lib.ptr(mel), _lib.ptr(align),
@@ -278,20 +344,52 @@ class Tacotron2:
         (Tacotron2/TTS/models.py:802-813): text LongTensor [B,T] ->
         (decoder_output [B,F,80], postnet_output [B,F,80], alignments [B,T_dec,T],
         stop_tokens [B,T_dec,1])."""
-        if speaker_ids is not None:
-            raise NotImplementedError("speaker embeddings are outside the accelerated path")
-        out = self.inference_batch(text)
+        out = self.inference_batch(text, speaker_ids=speaker_ids)
         return out["decoder_output"], out["postnet_output"], out["alignments"], out["stop_tokens"]
 
     @torch.no_grad()
-    def inference_batch(self, text, text_lengths=None, fixed_steps=None):
+    def inference_truncated(self, text, speaker_ids=None):
+        """Same contract as the reference `Tacotron2.inference_truncated`
+        (Tacotron2/TTS/models.py:815-829): the encoder BiLSTM state (:456-464), the decoder's
+        LSTM states and context (:675-686) and the fed-back frame survive from call to call;
+        the attention state is reset per call.  As in the reference the fed-back frame is the
+        whole decoder output (:703), which only fits the prenet at r = 1, and it is the frame
+        of the step BEFORE the one that ended the previous call (the assignment is skipped on
+        `break`)."""
+        self._require_device()
+        if self.decoder.r != 1:
+            raise RuntimeError("inference_truncated feeds the whole decoder output back: it needs r == 1")
+        text = torch.as_tensor(text).to(self.device).long()
+        if text.dim() != 2 or text.shape[0] != 1:
+            raise ValueError("text must be [1, T]")
+        first = self._rnn_state is None
+        if first:
+            self._rnn_state = (torch.zeros(2, 1, 256, device=self.device), torch.zeros(2, 1, 256, device=self.device))
+            self._memory_truncated = torch.zeros(1, 80, device=self.device)
+        enc = self.encode(text, None, speaker_ids, self._rnn_state)
+        mel, align, stop, n_steps, steps = self.decode(enc, None, None, keep_states=not first,
+                                                       memory=self._memory_truncated)
+        if steps == self.decoder.max_decoder_steps and float(stop[0, -1]) <= self.decoder.stop_threshold:
+            print("   | > Decoder stopped with 'max_decoder_steps")
+        if steps > 1:
+            self._memory_truncated = mel[:, steps - 2].clone()
+        post = self.postnet(mel)
+        return mel, post, align, stop.unsqueeze(-1)
+
+    def reset_truncated(self):
+        """Forget the state `inference_truncated` carries (a fresh reference model)."""
+        self._rnn_state = None
+        self._memory_truncated = None
+
+    @torch.no_grad()
+    def inference_batch(self, text, text_lengths=None, fixed_steps=None, speaker_ids=None):
         """Batched decode.  Each utterance's rows up to n_steps[b] equal what a
         batch-1 `inference` of that utterance returns; later rows are padding."""
         self._require_device()
         text = torch.as_tensor(text).to(self.device).long()
         if text.dim() != 2:
             raise ValueError("text must be [B, T]")
-        enc = self.encode(text, text_lengths)
+        enc = self.encode(text, text_lengths, speaker_ids)
         mel, align, stop, n_steps, steps = self.decode(enc, text_lengths, fixed_steps)
         if not fixed_steps and steps == self.decoder.max_decoder_steps and \
                 bool((stop[:, -1] <= self.decoder.stop_threshold).any()):
