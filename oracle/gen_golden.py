@@ -7,6 +7,7 @@ Usage (from the repo root, in the container that mounts /root/reference):
                                         # attention, speaker embedding, inference_truncated)
     python oracle/gen_golden.py t2audio # AudioProcessor pieces that run without librosa
     python oracle/gen_golden.py t1      # Tacotron (v1) model fixtures
+    python oracle/gen_golden.py text    # symbol tables, cleaners, number speller, id sequences
 
 Each family runs in its own process because both reference trees define a
 top-level package called `TTS`.  The reference never travels to the GPU box:
@@ -242,6 +243,53 @@ def gen_t1():
     print("t1_audio_pieces", ap.n_fft, ap.hop_length, ap.win_length)
 
 
+# ------------------------------------------------------------------ text front-end (pure-Python part)
+TEXT_LINES = [
+    "Hello, World!  This is   a test.",
+    "Dr. Smith paid $3.50 for 2 apples on the 21st of May, 1999.",
+    "Turn left on {HH AW1 S S T AH0 N} Street; it costs £1,200.",
+    "Mr. and Mrs. Jones live at 1500 St. James Rd., apt. 3rd floor?",
+    "It's 100% (almost) 0.75 - or 1,000,000: who knows~^_",
+    "Lt. Col. Brown owes $0.01, $1, $2.05 and $10.5.2 to Capt. Hook Jr.",
+    "12th 13th 101st 2000 2100 1000000000000000000 42",
+]
+PHONEME_LINES = ["h|ə|l|oʊ| |w|ɜː|l|d|!", "ð|ɪ|s| |ɪ|z| |ɐ| |t|ɛ|s|t|.", "ˈaɪ| |ˌɛ|m|~|^|_| |ʘ|ǃ|,"]
+G2P_CASES = [("hello, world. how are you?", "h|ə|l|oʊ| |\nw|ɜː|l|d| |\nh|aʊ| |ɑːɹ| |j|uː| |\n"),
+             ("no punctuation here", "n|oʊ| |p|ʌ|ŋ|k| |h|ɪɹ| |\n"),
+             ("first; second, third", "f|ɜː|s|t| |\ns|ɛ|k|ə|n|d| |\nθ|ɜː|d| |\n")]
+
+
+def gen_text():
+    _register_placeholders()
+    sys.path.insert(0, os.path.join(REF, "Tacotron2"))
+    from TTS import utils as U  # the reference implementation
+    out = dict(n_symbols=len(U.symbols), n_phonemes=len(U.phonemes), symbols=U.symbols, phonemes=U.phonemes, lines=[],
+               phoneme_lines=[], g2p=[])
+    for line in TEXT_LINES:
+        # the pipelines below are the reference's own cleaner functions; convert_to_ascii (unidecode, absent
+        # here) is left out, which changes nothing for ASCII input
+        eng = U.collapse_whitespace(U.expand_abbreviations(U.expand_numbers(U.lowercase(line))))
+        ids = U.text_to_sequence(line, ["basic_cleaners"])
+        out["lines"].append(dict(text=line, basic=U.basic_cleaners(line), english_ascii=eng,
+                                 numbers=U.normalize_numbers(line), abbreviations=U.expand_abbreviations(line),
+                                 basic_ids=ids, basic_text=U.sequence_to_text(ids)))
+    for ph in PHONEME_LINES:
+        ids = []
+        for chunk in filter(None, ph.split("|")):
+            ids += U._phoneme_to_sequence(chunk)
+        out["phoneme_lines"].append(dict(ph=ph, ids=ids, padded=U.pad_with_eos_bos(ids), text=U.sequence_to_phoneme(ids)))
+    # text2phone after the phonemizer call: give the reference a phonemizer output of the documented shape
+    # (a line break wherever espeak dropped sentence punctuation) and record what it rebuilds
+    for text, raw in G2P_CASES:
+        raw = raw.replace("\\n", "\n")
+        U.phonemize = lambda t, _raw=raw, **kw: _raw
+        U.phonemizer.separator = types.SimpleNamespace(Separator=lambda *a: None)
+        out["g2p"].append(dict(text=text, raw=raw, ph=U.text2phone(text, "en-us")))
+    with open(os.path.join(GOLD, "text_cases.json"), "w", encoding="utf8") as f:
+        json.dump(out, f, ensure_ascii=False, indent=1)
+    print("text_cases: %d symbols, %d phonemes" % (len(U.symbols), len(U.phonemes)))
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    {"t2": gen_t2, "t2v": gen_t2v, "t2audio": gen_t2audio, "t1": gen_t1}[sys.argv[1]]()
+    {"t2": gen_t2, "t2v": gen_t2v, "t2audio": gen_t2audio, "t1": gen_t1, "text": gen_text}[sys.argv[1]]()

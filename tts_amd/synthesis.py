@@ -1,18 +1,26 @@
 """Synthesis helpers with the reference's signatures (Tacotron2/TTS/utils.py:1422-1528).
 
-`text` may be a string only if a text front-end is supplied (`text_to_ids=`): the reference's
-front-end needs phonemizer + espeak, which is outside this path; an integer id sequence (list,
-ndarray or LongTensor) is accepted in place of the string and is what the tests use.
+`text` may be a string or an integer id sequence (list, ndarray or LongTensor; what the tests
+use).  Strings go through `tts_amd.text` as in the reference (utils.py:1423-1437): character ids
+when `use_phonemes` is false, phoneme ids otherwise - that branch needs a grapheme-to-phoneme
+backend (phonemizer + espeak, or `text_to_ids=`).
 """
 import numpy as np
 import torch
 
+from . import text as text_frontend
+
 
 def text_to_seqvec(text, CONFIG, use_cuda, text_to_ids=None):
     if isinstance(text, str):
-        if text_to_ids is None:
-            raise NotImplementedError("no text front-end: pass phoneme/character ids, or text_to_ids=")
-        seq = np.asarray(text_to_ids(text), dtype=np.int32)
+        cleaners = [CONFIG.get("text_cleaner") or "basic_cleaners"]
+        if text_to_ids is not None:
+            seq = np.asarray(text_to_ids(text), dtype=np.int32)
+        elif CONFIG.get("use_phonemes"):
+            seq = np.asarray(text_frontend.phoneme_to_sequence(text, cleaners, CONFIG.get("phoneme_language"),
+                                                               bool(CONFIG.get("enable_eos_bos_chars"))), dtype=np.int32)
+        else:
+            seq = np.asarray(text_frontend.text_to_sequence(text, cleaners), dtype=np.int32)
     else:
         seq = np.asarray(text, dtype=np.int32).reshape(-1)
     chars_var = torch.from_numpy(seq).unsqueeze(0)
@@ -25,7 +33,7 @@ def run_model(model, inputs, CONFIG, truncated, speaker_id=None, style_mel=None)
     if CONFIG.get("use_gst"):
         raise NotImplementedError("GST is outside the accelerated path")
     if truncated:
-        raise NotImplementedError("inference_truncated is outside the accelerated path")
+        return model.inference_truncated(inputs, speaker_ids=speaker_id)
     return model.inference(inputs, speaker_ids=speaker_id)
 
 
