@@ -202,6 +202,11 @@ struct GemmP {
   float* x1;      // PROJ: prenet layer-1 activations for the next step, quad layout
   int relu;       // LINEAR: apply ReLU
   int o_quads;    // PROJ: number of quads that are mel rows (80*r_init/4)
+  // LSTM (attention LSTM only): the workgroup also leaves its share of the query projection,
+  //   qpart[(g * Bpad + b) * 128 + d] = sum over the workgroup's hidden units u of wq_t[u][d] * h[u][b],
+  // g = index of the workgroup's unit group; the attention kernel adds the groups up
+  const float* wq_t;  // [1024][128] query_layer weight, transposed
+  float* qpart;
   RunCtx* ctx;
   int step_in_chunk;
 };
@@ -225,13 +230,14 @@ __device__ __forceinline__ Pre prefetch_quad(const GemmP& p, int quad, int b) {
 }
 
 // Finish one quad (4 consecutive output rows) of utterance column b.
+// (LSTM: returns the new hidden state of the pair, otherwise 0)
 template <int MODE>
-__device__ __forceinline__ void epilogue_quad(const GemmP& p, int quad, int b, f32x4 v, const Pre& pre) {
+__device__ __forceinline__ float epilogue_quad(const GemmP& p, int quad, int b, f32x4 v, const Pre& pre) {
   const int Bpad = p.Bpad;
   if (MODE == MODE_PARTIAL) {
     const int gp = p.gates_pitch ? p.gates_pitch : Bpad;
     reinterpret_cast<float4*>(p.gates)[(size_t)quad * gp + p.gates_col0 + b] = make_float4(v[0], v[1], v[2], v[3]);
-    return;
+    return 0.f;
   }
   v[0] += pre.bias.x, v[1] += pre.bias.y, v[2] += pre.bias.z, v[3] += pre.bias.w;
   if (MODE == MODE_LSTM) {
@@ -248,6 +254,7 @@ __device__ __forceinline__ void epilogue_quad(const GemmP& p, int quad, int b, f
     p.c[idx] = c_new;
     float* h_out = p.parity ? p.out[0] : p.out[1];
     h_out[idx] = h_new;
+    return h_new;
   } else if (MODE == MODE_LINEAR) {
     if (p.relu) v = (f32x4){fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
     reinterpret_cast<float4*>(p.out[0])[(size_t)quad * Bpad + b] = make_float4(v[0], v[1], v[2], v[3]);
@@ -277,6 +284,7 @@ __device__ __forceinline__ void epilogue_quad(const GemmP& p, int quad, int b, f
           make_float4(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f));
     }
   }
+  return 0.f;
 }
 
 // (selects, not an index into x[]: a dynamically indexed copy of the argument struct would be
@@ -331,6 +339,15 @@ struct GemmOp {
 #pragma unroll
       for (int n = 0; n < NT; ++n) xv[i][n] = xp[n * 16];
     }
+    // query-projection share: thread (d = tid & 127, cg = tid >> 7) covers columns cg*4*NT .. +4*NT-1
+    constexpr int QU = 4 * R, QC = 4 * NT;
+    float wq[QU];
+    const bool qshare = MODE == MODE_LSTM && p.qpart != nullptr;
+    if (qshare) {
+#pragma unroll
+      for (int j = 0; j < QU; ++j) wq[j] = p.wq_t[(size_t)(rb * 4 + j) * ATT_DIM + (threadIdx.x & (ATT_DIM - 1))];
+    }
+    __shared__ float s_h[QU][NT * 16];
     // epilogue operands of the tile(s) this wave finishes: tile t = r * NT + n
     Pre pre[TPW];
 #pragma unroll
@@ -380,7 +397,20 @@ struct GemmOp {
       f32x4 v = red[0][t][lane];
 #pragma unroll
       for (int w = 1; w < GEMM_WAVES; ++w) v += red[w][t][lane];
-      epilogue_quad<MODE>(p, (rb + t / NT) * 4 + (lane >> 4), b0 + (t % NT) * 16 + (lane & 15), v, pre[k]);
+      const float h = epilogue_quad<MODE>(p, (rb + t / NT) * 4 + (lane >> 4), b0 + (t % NT) * 16 + (lane & 15), v, pre[k]);
+      if (MODE == MODE_LSTM) s_h[(t / NT) * 4 + (lane >> 4)][(t % NT) * 16 + (lane & 15)] = h;
+    }
+    if (qshare) {
+      __syncthreads();
+      const int d = threadIdx.x & (ATT_DIM - 1), c0 = (threadIdx.x >> 7) * QC;
+      float* dst = p.qpart + ((size_t)(rb / R) * p.Bpad + b0 + c0) * ATT_DIM + d;
+#pragma unroll
+      for (int c = 0; c < QC; ++c) {
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < QU; ++j) acc += wq[j] * s_h[j][c0 + c];
+        dst[(size_t)c * ATT_DIM] = acc;
+      }
     }
   }
 };
@@ -416,6 +446,13 @@ struct GemvOp {
         }
       }
     }
+    const bool qshare = MODE == MODE_LSTM && p.qpart != nullptr;
+    float wq[4];
+    if (qshare && tid < ATT_DIM * NB) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wq[j] = p.wq_t[(size_t)(rb * 4 + j) * ATT_DIM + (tid & (ATT_DIM - 1))];
+    }
+    __shared__ float s_hq[4][NB];
     // epilogue operands: thread (qi, b) finishes quad qi of the row block for utterance b
     const int qi = tid / NB, eb = tid % NB, quad_e = rb * 4 + qi;
     Pre pre;
@@ -453,7 +490,18 @@ struct GemvOp {
         for (int w = 0; w < GEMM_WAVES; ++w) t += s_red[w][eb][qi * 4 + j];
         v[j] = t;
       }
-      epilogue_quad<MODE>(p, quad_e, eb, v, pre);
+      const float h = epilogue_quad<MODE>(p, quad_e, eb, v, pre);
+      if (MODE == MODE_LSTM) s_hq[qi][eb] = h;
+    }
+    if (qshare) {
+      __syncthreads();
+      if (tid < ATT_DIM * NB) {
+        const int d = tid & (ATT_DIM - 1), bb = tid >> 7;
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc += wq[j] * s_hq[j][bb];
+        p.qpart[((size_t)rb * NB + bb) * ATT_DIM + d] = acc;
+      }
     }
   }
 };
@@ -489,6 +537,11 @@ struct AttnP {
   RunCtx* ctx;
   int step_in_chunk, Bpad, norm, T;
   int gx;  // workgroups per utterance: workgroup id = b * gx + x
+  // fused kernel (FusedAttnOp) only
+  const float* qpart;   // [n_qgroups][Bpad][128] shares of the query projection left by the attention LSTM
+  int n_qgroups;
+  const float* wlc_p;   // [2][16][64]  location_conv weight as MFMA A-operand fragments
+  const float* wld_p;   // [8][8][64]   location_dense weight as MFMA A-operand fragments
   // optional attention variants (AttnPostOp / GravesOp only)
   int windowing, forward_attn, forward_attn_mask, trans_agent;
   int32_t* win_idx;     // [B] window centre of apply_windowing, -1 before the first step
@@ -743,10 +796,20 @@ __device__ __forceinline__ void block_context(const AttnP& p, int b, int len, co
   const int cl = tid % LPR, rg = tid / LPR;
   const float4* e4 = reinterpret_cast<const float4*>(p.enc + (size_t)b * T * ENC_DIM) + cl;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int t = rg; t < len; t += RG) {
-    const float4 v0 = e4[(size_t)t * (ENC_DIM / 4)];
-    const float a0 = s_al[t];
-    acc.x += a0 * v0.x, acc.y += a0 * v0.y, acc.z += a0 * v0.z, acc.w += a0 * v0.w;
+  // (eight independent row loads per pass: a rolled loop would pay one memory round trip per row)
+  for (int t0 = rg; t0 < len; t0 += 8 * RG) {
+    float4 v0[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int t = t0 + u * RG;
+      v0[u] = t < len ? e4[(size_t)t * (ENC_DIM / 4)] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int t = t0 + u * RG;
+      const float a0 = t < len ? s_al[t] : 0.f;
+      acc.x += a0 * v0[u].x, acc.y += a0 * v0[u].y, acc.z += a0 * v0[u].z, acc.w += a0 * v0[u].w;
+    }
   }
   __syncthreads();
   s_acc[tid] = acc;
@@ -941,6 +1004,232 @@ struct GravesOp {
   }
 };
 
+// The whole attention of one utterance in ONE workgroup, for encoder lengths up to 256: query (sum of
+// the shares the attention LSTM left), location features, energies, normalisation, alignment
+// outputs, context.  It replaces three launches of the serial chain (query, energies, context).
+// The two contractions run on the matrix cores, one wave per tile of 16 encoder positions:
+//   cf[f][t]  = sum_k W_lc[f][k] X[k][t],  X[k][t] = a_c[t + j - 15] (k = 31 c + j): a Toeplitz
+//               operand read straight from the zero-padded alignment rows in LDS  (32 MFMAs / tile)
+//   loc[d][t] = sum_f W_ld[d][f] cf[f][t]                                            (64 MFMAs / tile)
+// with the weights staged in LDS as A-operand fragments and cf handed from the first product to the
+// second through a wave-private LDS tile.  NTT = tiles per wave (1: T <= 128, 2: T <= 256).
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a workgroup fence, which
+// waits for every outstanding global load as well - including loads issued early on purpose.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+#ifdef TTSX_FA_TIMING
+// phase timestamps of workgroup 0 (100 MHz wall clock), for tuning builds only
+__device__ long long g_fa_t[8];
+#define FA_MARK(i) do { if (wg == 0 && threadIdx.x == 0) g_fa_t[i] = wall_clock64(); } while (0)
+#else
+#define FA_MARK(i) do { } while (0)
+#endif
+constexpr int FA_TMAX = 256, FA_CF_PITCH = 36, FA_SA_LEN = 304;
+constexpr int FA_LDS_FLOATS = 2048 + 4096 + 2 * FA_SA_LEN + GEMM_WAVES * 16 * FA_CF_PITCH + 512 + 128 + 128 + 256 + 256;
+template <int NTT>
+struct FusedAttnOp {
+  typedef AttnP P;
+  static __device__ __forceinline__ void run(const AttnP& p, int wg) {
+    RunCtx* cx = p.ctx;
+    const int done = cx->all_done;
+    const int T = p.T, b = wg, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int len = p.len[b];
+    extern __shared__ float s_dyn[];
+    float* s_wlc = s_dyn;                      // [2][16][64]
+    float* s_wld = s_wlc + 2048;               // [8][8][64]; the context partial sums reuse it
+    float* s_a = s_wld + 4096;                 // [2][FA_SA_LEN]: a_c[i - 15]
+    float* s_cf = s_a + 2 * FA_SA_LEN;         // [wave][16][FA_CF_PITCH]
+    float* s_q4 = s_cf + GEMM_WAVES * 16 * FA_CF_PITCH;  // (spare)
+    float* s_q = s_q4 + 512;                   // [128]
+    float* s_v = s_q + 128;                    // [128]
+    float* s_e = s_v + 128;                    // [256]
+    float* s_al = s_e + 256;                   // [256]
+    __shared__ float s_red[CTX_THREADS / 64];
+    FA_MARK(0);
+
+    // ---- loads.  Vector loads return in order, so what the first barrier needs is requested first
+    // (query shares, weight fragments, alignment rows) and the encoder rows of the context - 128 KB
+    // or more, wanted only at the very end - after it: the barrier then waits for the early group only.
+    // Query shares: a row of 128 floats is 32 float4 lanes; the 512 threads read 16 rows at a time.
+    constexpr int QROWS = CTX_THREADS / 32, QMAX = (QUERY_DIM / 4) / QROWS;  // 16 rows in parallel, <= 16 passes
+    float4 qv[QMAX];
+    {
+      const float4* qp = reinterpret_cast<const float4*>(p.qpart + (size_t)b * ATT_DIM) + (tid & 31);
+      const size_t gs = (size_t)p.Bpad * (ATT_DIM / 4);
+#pragma unroll
+      for (int u = 0; u < QMAX; ++u) {
+        // (unconditional loads from clamped addresses, masked when summed: a load under a lane
+        // condition becomes a branch, and the waits at its join serialise the whole load phase)
+        const int g = min((tid >> 5) + QROWS * u, p.n_qgroups - 1);
+        qv[u] = qp[(size_t)g * gs];
+      }
+    }
+    const float4 w0 = reinterpret_cast<const float4*>(p.wlc_p)[tid];
+    const float4 w1 = reinterpret_cast<const float4*>(p.wld_p)[tid];
+    const float4 w2 = reinterpret_cast<const float4*>(p.wld_p)[tid + 512];
+    float sa[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int i = tid + u * CTX_THREADS;
+      const int c = i >= FA_SA_LEN ? 1 : 0, t = i - c * FA_SA_LEN - ATT_PAD;
+      const float* src = c ? p.a_cum : p.a_prev;
+      const float val = src[(size_t)b * T + min(max(t, 0), T - 1)];
+      sa[u] = (i < 2 * FA_SA_LEN && t >= 0 && t < T) ? val : 0.f;
+    }
+    const float vw = p.v_w[tid & (ATT_DIM - 1)];
+    const float vb = p.v_b[0];
+    // ---- stage the early group
+    {
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int u = 0; u < QMAX; ++u) {
+        const float on = (tid >> 5) + QROWS * u < p.n_qgroups ? 1.f : 0.f;
+        acc.x += on * qv[u].x, acc.y += on * qv[u].y, acc.z += on * qv[u].z, acc.w += on * qv[u].w;
+      }
+      reinterpret_cast<float4*>(s_cf)[tid] = acc;  // [16 rows][32 float4]: partial sums by row group
+    }
+    reinterpret_cast<float4*>(s_wlc)[tid] = w0;
+    reinterpret_cast<float4*>(s_wld)[tid] = w1;
+    reinterpret_cast<float4*>(s_wld)[tid + 512] = w2;
+    s_a[tid] = sa[0];
+    if (tid + CTX_THREADS < 2 * FA_SA_LEN) s_a[tid + CTX_THREADS] = sa[1];
+    if (tid < ATT_DIM) s_v[tid] = vw;
+    __syncthreads();
+    FA_MARK(1);
+    // The encoder rows of the first 128 positions are requested now and wait in registers (one
+    // workgroup per CU: the register file is otherwise idle), so the context costs no memory round
+    // trip at the end.  Not earlier: vector loads return in order and the barrier above would have
+    // waited for these 128 KB as well (measured: 4.3 us instead of 2.1 us to reach it).
+    constexpr int LPR = ENC_DIM / 4, RG = CTX_THREADS / LPR;
+    const int cl = tid % LPR, rg = tid / LPR;
+    const float4* e4 = reinterpret_cast<const float4*>(p.enc + (size_t)b * T * ENC_DIM) + cl;
+    constexpr int FA_PRE = NTT == 1 ? 32 : 16;  // (two tiles per wave leave fewer registers free)
+    float4 pre[FA_PRE];
+    const int t_last = max(len - 1, 0);
+#pragma unroll
+    for (int i = 0; i < FA_PRE; ++i) pre[i] = e4[(size_t)min(rg + i * RG, t_last) * (ENC_DIM / 4)];  // (masked at use)
+    if (tid < ATT_DIM) {
+      float acc = 0.f;
+#pragma unroll
+      for (int r = 0; r < QROWS; ++r) acc += s_cf[r * ATT_DIM + tid];
+      s_q[tid] = acc;
+    }
+    lds_barrier();  // (the encoder-row loads stay in flight)
+    FA_MARK(2);
+
+    // ---- energies, one tile of 16 positions per wave and pass
+    const int ntt = (T + 15) >> 4, lq = lane >> 4, lt = lane & 15;
+    float* cfw = s_cf + wave * 16 * FA_CF_PITCH;
+#pragma unroll
+    for (int i = 0; i < NTT; ++i) {
+      const int tt = wave + GEMM_WAVES * i;
+      if (tt >= ntt) break;  // wave-uniform; no workgroup barrier inside this loop
+      const int t = 16 * tt + lt;
+      const float* Prow = p.P + ((size_t)b * T + (t < T ? t : 0)) * ATT_DIM + 4 * lq;
+      float4 pv[8];
+#pragma unroll
+      for (int dt = 0; dt < 8; ++dt) pv[dt] = *reinterpret_cast<const float4*>(Prow + 16 * dt);
+      f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) {
+        const int k = 16 * (kk >> 2) + 4 * lq + (kk & 3);
+        const int c = k >= LOC_K ? 1 : 0, j = k - LOC_K * c;  // (k = 62, 63: zero weight, any finite operand)
+        const float xv = s_a[c * FA_SA_LEN + 16 * tt + lt + j];
+        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(s_wlc[kk * 64 + lane], xv, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(s_wlc[(16 + kk) * 64 + lane], xv, c1, 0, 0, 0);
+      }
+      *reinterpret_cast<float4*>(&cfw[lt * FA_CF_PITCH + 4 * lq]) = make_float4(c0[0], c0[1], c0[2], c0[3]);
+      *reinterpret_cast<float4*>(&cfw[lt * FA_CF_PITCH + 16 + 4 * lq]) = make_float4(c1[0], c1[1], c1[2], c1[3]);
+      __builtin_amdgcn_wave_barrier();
+      const float4 bq0 = *reinterpret_cast<const float4*>(&cfw[lt * FA_CF_PITCH + 4 * lq]);
+      const float4 bq1 = *reinterpret_cast<const float4*>(&cfw[lt * FA_CF_PITCH + 16 + 4 * lq]);
+      float esum = 0.f;
+#pragma unroll
+      for (int dt = 0; dt < 8; ++dt) {
+        const float* wa = s_wld + dt * 8 * 64 + lane;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[0 * 64], bq0.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[1 * 64], bq0.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[2 * 64], bq0.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[3 * 64], bq0.w, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[4 * 64], bq1.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[5 * 64], bq1.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[6 * 64], bq1.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[7 * 64], bq1.w, acc, 0, 0, 0);
+        const float4 qv = *reinterpret_cast<const float4*>(&s_q[16 * dt + 4 * lq]);
+        const float4 vv = *reinterpret_cast<const float4*>(&s_v[16 * dt + 4 * lq]);
+        esum += vv.x * fast_tanhf(qv.x + acc[0] + pv[dt].x) + vv.y * fast_tanhf(qv.y + acc[1] + pv[dt].y) +
+                vv.z * fast_tanhf(qv.z + acc[2] + pv[dt].z) + vv.w * fast_tanhf(qv.w + acc[3] + pv[dt].w);
+      }
+      esum += __shfl_xor(esum, 16, 64);
+      esum += __shfl_xor(esum, 32, 64);
+      if (lane < 16 && t < FA_TMAX) s_e[t] = esum + vb;
+      __builtin_amdgcn_wave_barrier();
+    }
+    lds_barrier();
+    FA_MARK(3);
+
+    // ---- normalisation over the utterance's own positions
+    const bool softmax = p.norm == TTSX_NORM_SOFTMAX;
+    float m = 0.f;
+    if (softmax) {
+      m = tid < len ? s_e[tid] : -INFINITY;
+      m = block_max(m, s_red);
+    }
+    float v = 0.f;
+    if (tid < len) v = softmax ? expf(s_e[tid] - m) : sigmoidf_(s_e[tid]);
+    const float sum = block_sum(v, s_red);
+    const float a = v / sum;
+    if (tid < FA_TMAX) s_al[tid] = a;
+    __syncthreads();
+    FA_MARK(4);
+    if (done) return;
+    if (tid < T) {
+      const int row = cx->out_base + p.step_in_chunk;
+      p.a_prev[(size_t)b * T + tid] = a;
+      p.a_cum[(size_t)b * T + tid] = s_a[FA_SA_LEN + ATT_PAD + tid] + a;
+      cx->align[((size_t)b * cx->align_rows + row) * T + tid] = a;
+    }
+    // ---- context
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < FA_PRE; ++i) {
+      const int t = rg + i * RG;
+      const float a0 = t < len ? s_al[t] : 0.f;
+      acc.x += a0 * pre[i].x, acc.y += a0 * pre[i].y, acc.z += a0 * pre[i].z, acc.w += a0 * pre[i].w;
+    }
+    if (NTT > 1) {
+      // the remaining positions, in batches of independent row loads
+#pragma unroll 1
+      for (int base = FA_PRE; base < FA_TMAX / RG; base += FA_PRE) {
+        if (base * RG >= len) break;
+#pragma unroll
+        for (int i = 0; i < FA_PRE; ++i) pre[i] = e4[(size_t)min(rg + (base + i) * RG, t_last) * (ENC_DIM / 4)];
+#pragma unroll
+        for (int i = 0; i < FA_PRE; ++i) {
+          const int t = rg + (base + i) * RG;
+          const float a0 = t < len ? s_al[t] : 0.f;
+          acc.x += a0 * pre[i].x, acc.y += a0 * pre[i].y, acc.z += a0 * pre[i].z, acc.w += a0 * pre[i].w;
+        }
+      }
+    }
+    float4* s_acc = reinterpret_cast<float4*>(s_wld);  // the dense weights are no longer needed
+    s_acc[tid] = acc;
+    FA_MARK(5);
+    __syncthreads();
+    if (tid < LPR) {
+      float4 tot = s_acc[tid];
+#pragma unroll
+      for (int g = 1; g < RG; ++g) {
+        const float4 w = s_acc[g * LPR + tid];
+        tot.x += w.x, tot.y += w.y, tot.z += w.z, tot.w += w.w;
+      }
+      reinterpret_cast<float4*>(p.ctx_out)[(size_t)tid * p.Bpad + b] = tot;
+    }
+    FA_MARK(6);
+  }
+};
+
 // processed_inputs P[b][t][d] = sum_c enc[b][t][c] * w_in[d][c]
 // (OriginalAttention.preprocess_inputs, once per utterance).
 __global__ __launch_bounds__(256) void inputs_proj_kernel(float* __restrict__ P, const float* __restrict__ enc,
@@ -986,6 +1275,31 @@ __global__ void transpose_loc_kernel(float* __restrict__ conv_t, float* __restri
   if (i < ATT_DIM * LOC_F) {
     const int d = i / LOC_F, f = i % LOC_F;
     dense_t[((f >> 2) * ATT_DIM + d) * 4 + (f & 3)] = dense_w[i];
+  }
+}
+
+// location-layer weights as A-operand fragments of v_mfma_f32_16x16x4_f32 (lane l: row l&15, issue
+// kk covers k = 16*(kk>>2) + 4*(l>>4) + (kk&3)):
+//   wlc_p[(ft*16 + kk)*64 + l] = W_lc[16 ft + (l&15)][k]   (k = channel*31 + tap, zero for k >= 62)
+//   wld_p[(dt*8  + kk)*64 + l] = W_ld[16 dt + (l&15)][k]   (k = filter)
+// and the query weight transposed, wq_t[u][d] = W_q[d][u].
+__global__ void pack_attn_frag_kernel(float* __restrict__ wlc_p, float* __restrict__ wld_p, float* __restrict__ wq_t,
+                                      const float* __restrict__ conv_w, const float* __restrict__ dense_w,
+                                      const float* __restrict__ query_w) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 2 * 16 * 64) {
+    const int l = i & 63, kk = (i >> 6) & 15, ft = i >> 10;
+    const int k = 16 * (kk >> 2) + 4 * (l >> 4) + (kk & 3), f = 16 * ft + (l & 15);
+    wlc_p[i] = (conv_w && k < 2 * LOC_K) ? conv_w[f * 2 * LOC_K + k] : 0.f;
+  }
+  if (i < 8 * 8 * 64) {
+    const int l = i & 63, kk = (i >> 6) & 7, dt = i >> 9;
+    const int k = 16 * (kk >> 2) + 4 * (l >> 4) + (kk & 3), dd = 16 * dt + (l & 15);
+    wld_p[i] = dense_w ? dense_w[dd * LOC_F + k] : 0.f;
+  }
+  if (i < QUERY_DIM * ATT_DIM) {
+    const int u = i / ATT_DIM, dd = i % ATT_DIM;
+    wq_t[i] = query_w[(size_t)dd * QUERY_DIM + u];
   }
 }
 
@@ -1054,6 +1368,10 @@ struct ttsx_t2_decoder {
   float *w_proj, *b_proj;  // mel rows + composed rows, valid for proj_r
   int proj_r;
   float *inputs_w, *v_w, *v_b, *loc_conv_w, *loc_dense_w;
+  float *wlc_p, *wld_p, *wq_t;  // fused attention kernel: MFMA fragments of the location layer, W_q transposed
+  float* qpart;                 // workspace: shares of the query projection, [groups][Bpad][128]
+  int qpart_groups;
+  bool fused;                   // this run uses the fused attention kernel (T <= 256, no variant)
   // optional attention variants
   bool variant;      // any of windowing / forward attention: the one-workgroup-per-utterance tail
   int windowing, forward_attn, forward_attn_mask, trans_agent, graves_K;
@@ -1082,12 +1400,15 @@ struct ttsx_t2_decoder {
   // cached chunk graph
   hipGraphExec_t graph;
   hipStream_t cap_stream;  // capture-only stream: the caller's stream may be the legacy default stream
-  int g_B, g_T, g_r, g_gen, g_chunk, g_split;
+  int g_B, g_T, g_r, g_gen, g_chunk, g_split, g_fused;
 };
 
 namespace {
 
 constexpr int CHUNK = 32;
+int gemm_shape(int Bpad, int nrb);
+int query_groups(int B, int Bpad);
+hipError_t set_fused_lds();
 
 template <typename T>
 int dev_alloc(T** p, size_t n) {
@@ -1139,7 +1460,7 @@ void free_len_workspace(ttsx_t2_decoder* d) {
 void free_workspace(ttsx_t2_decoder* d) {
   free_len_workspace(d);
   float** bufs[] = {&d->x1, &d->x2, &d->ctx, &d->h_a[0], &d->h_a[1], &d->c_a, &d->h_d[0], &d->h_d[1], &d->c_d,
-                    &d->q,  &d->o,  &d->g_a, &d->g_d, &d->u_fa, &d->mu, &d->n1, &d->gbk};
+                    &d->q,  &d->o,  &d->g_a, &d->g_d, &d->u_fa, &d->mu, &d->n1, &d->gbk, &d->qpart};
   for (float** b : bufs) {
     if (*b) (void)hipFree(*b);
     *b = nullptr;
@@ -1180,6 +1501,8 @@ int ensure_workspace(ttsx_t2_decoder* d, int B, int T) {
     rc |= dev_alloc(&d->mu, cb * GRAVES_MAX_K);
     rc |= dev_alloc(&d->n1, QUERY_DIM * cb);
     rc |= dev_alloc(&d->gbk, (size_t)round_up(3 * GRAVES_MAX_K, 16) * cb);
+    d->qpart_groups = query_groups(B, Bpad);
+    rc |= dev_alloc(&d->qpart, (size_t)d->qpart_groups * cb * ATT_DIM);
     if (rc) return TTSX_ERR_HIP;
     d->cap_B = Bpad;
     d->ws_gen += 1;
@@ -1263,6 +1586,26 @@ int launch_with_piece(const ttsx_t2_decoder* d, const typename A::P& pa, int na,
 // A GEMM/GEMV launch on the serial path (`g` covers all `nrb` row blocks) with an optional piece.
 // KGW = k-groups per wave of the main op; `big`: a weight-streaming launch (LSTM) as opposed to one
 // of the small ones, which need many workgroups more than they need reuse.
+// Tile of a weight-streaming launch: R row blocks x NT column tiles per workgroup, code 10 R + NT.
+// Bigger tiles re-read fewer activations, but the launch must still cover the chip: take the
+// biggest tile that leaves at least one workgroup per CU (measured at batch 16..128).
+int gemm_shape(int Bpad, int nrb) {
+  const int nt_total = Bpad / 16;
+  int shape = 11;
+  const int cus = 256;
+  if (nrb % 2 == 0 && nrb / 2 * nt_total >= cus) shape = 21;
+  if (nrb % 2 == 0 && nt_total % 2 == 0 && nrb / 2 * (nt_total / 2) >= cus) shape = 22;
+  if (nrb % 4 == 0 && nt_total % 2 == 0 && nrb / 4 * (nt_total / 2) >= cus) shape = 42;
+  if (const char* e = getenv("TTSX_GEMM_SHAPE")) shape = atoi(e);  // tuning override
+  if (shape != 21 && shape != 22 && shape != 42 && shape != 24) shape = 11;
+  return shape;
+}
+// unit groups of the attention LSTM launch (= workgroups along the row axis): one share of the query each
+int query_groups(int B, int Bpad) {
+  if (B <= GEMV_MAX_B) return QUERY_DIM / 4;
+  return QUERY_DIM / 4 / (gemm_shape(Bpad, QUERY_DIM / 4) / 10);
+}
+
 template <int MODE, int KGW, int PK>
 int launch_gemm(const ttsx_t2_decoder* d, GemmP g, int nrb, bool big, const Piece* pc, hipStream_t st) {
   g.rb0 = 0, g.nrb = nrb;
@@ -1272,15 +1615,7 @@ int launch_gemm(const ttsx_t2_decoder* d, GemmP g, int nrb, bool big, const Piec
   }
   const int nt_total = d->Bpad / 16;
   if (!big) return launch_with_piece<GemmOp<1, 1, KGW, MODE>, PK>(d, g, nrb * nt_total, 0, nullptr, st);
-  // Tile of a weight-streaming launch: R row blocks x NT column tiles per workgroup, code 10 R + NT.
-  // Bigger tiles re-read fewer activations, but the launch must still cover the chip: take the
-  // biggest tile that leaves at least one workgroup per CU (measured at batch 16..128).
-  int shape = 11;
-  const int cus = 256;
-  if (nrb % 2 == 0 && nrb / 2 * nt_total >= cus) shape = 21;
-  if (nrb % 2 == 0 && nt_total % 2 == 0 && nrb / 2 * (nt_total / 2) >= cus) shape = 22;
-  if (nrb % 4 == 0 && nt_total % 2 == 0 && nrb / 4 * (nt_total / 2) >= cus) shape = 42;
-  if (const char* e = getenv("TTSX_GEMM_SHAPE")) shape = atoi(e);  // tuning override
+  const int shape = gemm_shape(d->Bpad, nrb);
   switch (shape) {
     case 21: return launch_with_piece<GemmOp<2, 1, KGW, MODE>, PK>(d, g, nrb / 2 * nt_total, 0, nullptr, st);
     case 22: return launch_with_piece<GemmOp<2, 2, KGW, MODE>, PK>(d, g, nrb / 2 * (nt_total / 2), 0, nullptr, st);
@@ -1315,6 +1650,23 @@ hipError_t set_context_lds(size_t bytes) {
   if ((e = set_context_lds_for<NoOp>(bytes)) != hipSuccess) return e;
   if ((e = set_context_lds_for<GemvOp<1, PK2, MODE_PARTIAL>>(bytes)) != hipSuccess) return e;
   return set_context_lds_for<GemvOp<2, PK2, MODE_PARTIAL>>(bytes);
+}
+
+// The fused attention kernel keeps ~50 KB of dynamic LDS beside the static arrays of its launch partner.
+template <class A>
+hipError_t set_fused_lds_for() {
+  const int bytes = FA_LDS_FLOATS * (int)sizeof(float);
+  hipError_t e;
+  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(dual_kernel<A, NoOp>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, bytes)) != hipSuccess) return e;
+  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(dual_kernel<A, GemvOp<1, PK2, MODE_PARTIAL>>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, bytes)) != hipSuccess) return e;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(dual_kernel<A, GemvOp<2, PK2, MODE_PARTIAL>>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+hipError_t set_fused_lds() {
+  hipError_t e = set_fused_lds_for<FusedAttnOp<1>>();
+  return e != hipSuccess ? e : set_fused_lds_for<FusedAttnOp<2>>();
 }
 
 // Early columns of the attention LSTM, [ctx(t-1); h_a(t-1)] -> g_a, for the step with chunk index i.
@@ -1371,6 +1723,7 @@ int enqueue_step(ttsx_t2_decoder* d, int i, bool first, bool more, hipStream_t s
   g.seg[1] = Seg{{d->ctx, nullptr}, 0, ENC_DIM / 16};
   g.seg[2] = Seg{{d->h_a[0], d->h_a[1]}, 1, QUERY_DIM / 16};
   g.out[0] = d->h_a[0], g.out[1] = d->h_a[1], g.c = d->c_a, g.relu = 0;
+  if (d->fused) g.wq_t = d->wq_t, g.qpart = d->qpart;  // the launch also leaves the shares of the query
   if (split) {
     g.nseg = 1, g.KG = PRENET_DIM / 16, g.gates = d->g_a;
     rc = launch_gemm<MODE_LSTM, 2, PK1>(d, g, QUERY_DIM / 4, true, nullptr, st);
@@ -1379,6 +1732,7 @@ int enqueue_step(ttsx_t2_decoder* d, int i, bool first, bool more, hipStream_t s
     rc = launch_gemm<MODE_LSTM, KG1 / GEMM_WAVES, PK1>(d, g, QUERY_DIM / 4, true, nullptr, st);
   }
   if (rc) return rc;
+  g.wq_t = nullptr, g.qpart = nullptr;
   AttnP ap{};
   ap.q = d->q, ap.P = d->P;
   ap.loc_conv_t = d->loc_conv_w, ap.loc_dense_t = d->loc_dense_w, ap.v_w = d->v_w, ap.v_b = d->v_b;
@@ -1401,6 +1755,15 @@ int enqueue_step(ttsx_t2_decoder* d, int i, bool first, bool more, hipStream_t s
     g.out[0] = d->gbk, g.relu = 0;
     if ((rc = launch_gemm<MODE_LINEAR, 8, PK2>(d, g, ceil_div(3 * d->graves_K, 16), false, nullptr, st))) return rc;
     if ((rc = launch_with_piece<GravesOp, PK2>(d, ap, B, sizeof(float) * (2 * T + 1), nullptr, st))) return rc;
+  } else if (d->fused) {
+    // query sum + energies + normalisation + context in one launch   (+ the whole decoder partial)
+    ap.qpart = d->qpart, ap.n_qgroups = d->qpart_groups, ap.wlc_p = d->wlc_p, ap.wld_p = d->wld_p;
+    pc = Piece{pd.g, split};
+    pc.g.rb0 = 0, pc.g.nrb = pd.total_rb;
+    const size_t smem = sizeof(float) * FA_LDS_FLOATS;
+    if (T <= 128) rc = launch_with_piece<FusedAttnOp<1>, PK2>(d, ap, B, smem, &pc, st);
+    else rc = launch_with_piece<FusedAttnOp<2>, PK2>(d, ap, B, smem, &pc, st);
+    if (rc) return rc;
   } else {
   // query projection   (+ first third of the decoder partial)
   g.Wp = d->w_query, g.bias = d->b_query, g.nseg = 1, g.KG = QUERY_DIM / 16, g.kg0 = 0, g.kg_stride = g.KG;
@@ -1473,7 +1836,8 @@ int push_ctx(ttsx_t2_decoder* d, hipStream_t st) {
 // Launch `n` steps as one graph (captured once per (B, T, r, workspace) and chunk size).
 int launch_chunk(ttsx_t2_decoder* d, int n, hipStream_t st) {
   const bool cached = d->graph && d->g_B == d->B && d->g_T == d->T && d->g_r == d->rc_host->r &&
-                      d->g_gen == d->ws_gen && d->g_chunk == n && d->g_split == (int)d->split;
+                      d->g_gen == d->ws_gen && d->g_chunk == n && d->g_split == (int)d->split &&
+                      d->g_fused == (int)d->fused;
   if (!cached && n == CHUNK) {
     drop_graph(d);
     hipGraph_t graph = nullptr;
@@ -1491,7 +1855,7 @@ int launch_chunk(ttsx_t2_decoder* d, int n, hipStream_t st) {
     TTSX_HIP(hipGraphInstantiate(&d->graph, graph, nullptr, nullptr, 0));
     (void)hipGraphDestroy(graph);
     d->g_B = d->B, d->g_T = d->T, d->g_r = d->rc_host->r, d->g_gen = d->ws_gen, d->g_chunk = n;
-    d->g_split = d->split;
+    d->g_split = d->split, d->g_fused = d->fused;
   }
   if (n == CHUNK) {
     TTSX_HIP(hipGraphLaunch(d->graph, st));
@@ -1567,6 +1931,15 @@ extern "C" int ttsx_t2_decoder_create(const ttsx_t2_decoder_weights* w, int r_in
     TTSX_HIP(hipMemsetAsync(d->loc_conv_w, 0, sizeof(float) * LOC_F * 2 * LOC_K, st));
     TTSX_HIP(hipMemsetAsync(d->loc_dense_w, 0, sizeof(float) * ATT_DIM * LOC_F, st));
   }
+  if (w->query_w) {
+    if (dev_alloc(&d->wlc_p, 2 * 16 * 64) || dev_alloc(&d->wld_p, 8 * 8 * 64) ||
+        dev_alloc(&d->wq_t, (size_t)QUERY_DIM * ATT_DIM))
+      return TTSX_ERR_HIP;
+    pack_attn_frag_kernel<<<ceil_div(QUERY_DIM * ATT_DIM, 256), 256, 0, st>>>(
+        d->wlc_p, d->wld_p, d->wq_t, w->loc_conv_w, w->loc_conv_w ? w->loc_dense_w : nullptr, w->query_w);
+    TTSX_LAUNCH_CHECK();
+    TTSX_HIP(set_fused_lds());
+  }
   TTSX_HIP(hipMalloc(reinterpret_cast<void**>(&d->rc), sizeof(RunCtx)));
   TTSX_HIP(hipMemsetAsync(d->rc, 0, sizeof(RunCtx), st));
   TTSX_HIP(hipHostMalloc(reinterpret_cast<void**>(&d->rc_host), sizeof(RunCtx), hipHostMallocDefault));
@@ -1587,7 +1960,7 @@ extern "C" int ttsx_t2_decoder_destroy(ttsx_t2_decoder* d) {
   float* bufs[] = {d->w_lstm1, d->b_lstm1, d->w_lstm2, d->b_lstm2, d->w_query, d->b_query,
                    d->w_pre2,  d->b_pre2,  d->w_proj,  d->b_proj,  d->proj_w_src, d->proj_b_src, d->stop_w_src,
                    d->stop_b_src, d->a1f, d->b1f, d->inputs_w, d->v_w, d->v_b, d->loc_conv_w, d->loc_dense_w,
-                   d->ta_w, d->ta_b, d->w_na1, d->b_na1, d->w_na2, d->b_na2, d->mem0};
+                   d->ta_w, d->ta_b, d->w_na1, d->b_na1, d->w_na2, d->b_na2, d->mem0, d->wlc_p, d->wld_p, d->wq_t};
   for (float* b : bufs)
     if (b) (void)hipFree(b);
   if (d->cap_stream) (void)hipStreamDestroy(d->cap_stream);
@@ -1684,6 +2057,14 @@ extern "C" int ttsx_t2_decoder_begin(ttsx_t2_decoder* d, const float* enc, const
     // on the MFMA path, where the pieces cost a full activation pass each); TTSX_SPLIT=0 turns it off
     const char* e = getenv("TTSX_SPLIT");
     d->split = B <= GEMV_MAX_B && !(e && e[0] == '0') && !d->variant && !graves;
+    // One-workgroup-per-utterance attention for batches on the MFMA engine and encoder lengths up to
+    // 256 (TTSX_FUSED_ATTN=0: the three-launch path that longer texts take; =1 forces it at batch
+    // 1-2 as well).  Measured per step, fused / three launches: B=16 37.9 / 40.7 us, B=64 51.3 / 54.5,
+    // B=128 79.4 / 87.0, B=64 T=256 58.3 / 62.9; at B=1 it is a tie (32.8 / 33.0): the kernel moves
+    // ~260 KB through ONE CU's vector memory pipe and that costs what the two saved launches did.
+    const char* f = getenv("TTSX_FUSED_ATTN");
+    d->fused = T <= FA_TMAX && !d->variant && !graves && !(f && f[0] == '0') &&
+               (B > GEMV_MAX_B || (f && f[0] == '1'));
   }
   d->parity0 = 0;
   const size_t cb = d->Bpad;
@@ -2067,3 +2448,10 @@ extern "C" int ttsx_add_speaker_embedding(float* enc, const float* table, const 
   TTSX_LAUNCH_CHECK();
   return TTSX_OK;
 }
+
+#ifdef TTSX_FA_TIMING
+extern "C" int ttsx_debug_fa_timing(long long* out_host) {
+  TTSX_HIP(hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_fa_t), sizeof(long long) * 8));
+  return TTSX_OK;
+}
+#endif
