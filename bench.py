@@ -183,7 +183,8 @@ def main():
         if (pmc.get("B"), pmc.get("T")) == (B, T):
             roof["traffic"] = pmc["hbm_bytes_per_step"]
             roof["traffic_source"] = "profiles/r1_decoder_pmc.csv"
-    roof["kernel"] = "t2 decoder step (7 launches: prenet-2, attention LSTM, query, energies, context, decoder LSTM, projection)"
+    roof["kernel"] = ("t2 decoder step (5 launches: prenet-2, attention LSTM + query shares, fused attention, "
+                      "decoder LSTM, projection)")
     roof["us_per_launch_group"] = dec_us
     roof["algorithmic_bytes"] = nbytes
     roof["algorithmic_flops"] = flops
