@@ -1099,7 +1099,7 @@ struct FusedAttnOp {
     // The encoder rows of the first 128 positions are requested now and wait in registers (one
     // workgroup per CU: the register file is otherwise idle), so the context costs no memory round
     // trip at the end.  Not earlier: vector loads return in order and the barrier above would have
-    // waited for these 128 KB as well (measured: 4.3 us instead of 2.1 us to reach it).
+    // waited for these 256 KB as well (measured: 4.3 us instead of 2.1 us to reach it).
     constexpr int LPR = ENC_DIM / 4, RG = CTX_THREADS / LPR;
     const int cl = tid % LPR, rg = tid / LPR;
     const float4* e4 = reinterpret_cast<const float4*>(p.enc + (size_t)b * T * ENC_DIM) + cl;
