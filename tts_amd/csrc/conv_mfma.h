@@ -124,22 +124,31 @@ static __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvP p) {
   const float4* W0 = reinterpret_cast<const float4*>(p.wp) + (size_t)(has_cb[0] ? cb0 : 0) * p.NC * 64 + lane;
   const float4* W1 = reinterpret_cast<const float4*>(p.wp) + (size_t)(has_cb[1] ? cb0 + 1 : 0) * p.NC * 64 + lane;
   const int chunks_per_tap = p.Cin / 8;
-  const float* xbase[2] = {p.x + (size_t)bb[0] * p.F * p.x_pitch + 4 * half, p.x + (size_t)bb[1] * p.F * p.x_pitch + 4 * half};
+  // (columns past the last utterance read utterance B-1 and are masked: nf = 0)
+  const float* xbase[2] = {p.x + (size_t)min(bb[0], p.B - 1) * p.F * p.x_pitch + 4 * half,
+                           p.x + (size_t)min(bb[1], p.B - 1) * p.F * p.x_pitch + 4 * half};
 
   // operands of K chunk c (8 wide): two weight fragments, two activation fragments (zero outside the utterance)
   struct Frag {
     float4 a0, a1, x0, x1;
   };
+  // (Loads are unconditional, from clamped addresses, and masked afterwards: a load under a lane
+  // condition compiles to a branch whose join waits for every outstanding load, which serialises
+  // the software pipeline.)
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
   auto load = [&](int c, int tap, int cc) -> Frag {
     Frag f;
-    f.a0 = make_float4(0.f, 0.f, 0.f, 0.f), f.a1 = f.a0, f.x0 = f.a0, f.x1 = f.a0;
-    if (c < p.NC) {
-      f.a0 = W0[(size_t)c * 64];
-      f.a1 = W1[(size_t)c * 64];
-      const int fs0 = ff[0] + tap - p.pad_left, fs1 = ff[1] + tap - p.pad_left;
-      if (fs0 >= 0 && fs0 < nf[0]) f.x0 = *reinterpret_cast<const float4*>(xbase[0] + (size_t)fs0 * p.x_pitch + cc * 8);
-      if (fs1 >= 0 && fs1 < nf[1]) f.x1 = *reinterpret_cast<const float4*>(xbase[1] + (size_t)fs1 * p.x_pitch + cc * 8);
-    }
+    const bool in_k = c < p.NC;
+    const int cl = in_k ? c : p.NC - 1;
+    if (!in_k) tap = p.taps - 1, cc = chunks_per_tap - 1;
+    f.a0 = W0[(size_t)cl * 64];
+    f.a1 = W1[(size_t)cl * 64];
+    const int fs0 = ff[0] + tap - p.pad_left, fs1 = ff[1] + tap - p.pad_left;
+    const int fc0 = min(max(fs0, 0), p.F - 1), fc1 = min(max(fs1, 0), p.F - 1);
+    const float4 x0 = *reinterpret_cast<const float4*>(xbase[0] + (size_t)fc0 * p.x_pitch + cc * 8);
+    const float4 x1 = *reinterpret_cast<const float4*>(xbase[1] + (size_t)fc1 * p.x_pitch + cc * 8);
+    f.x0 = (in_k && fs0 >= 0 && fs0 < nf[0]) ? x0 : zero4;
+    f.x1 = (in_k && fs1 >= 0 && fs1 < nf[1]) ? x1 : zero4;
     return f;
   };
 #define TTSX_MFMA4(A, X, ACC)                                         \

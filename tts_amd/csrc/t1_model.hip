@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "conv_mfma.h"
+#include "t1_steps.h"
 
 using convmfma::Layer;
 
@@ -516,6 +517,7 @@ __global__ void transpose_loc_conv_kernel(float* __restrict__ conv_t, const floa
 
 struct ttsx_t1 {
   int r, memory_size, linear_dim;
+  t1_steps* steps;  // decoder as a chain of launches over the whole chip (null: memory queue too long for it)
   Layer enc_pre[2], annot, last;
   Cbhg enc_cbhg, post_cbhg;
   // decoder weights (own copies, reference layouts)
@@ -602,6 +604,22 @@ extern "C" int ttsx_t1_create(const ttsx_t1_weights* w, int r, int memory_size, 
     m->owned.push_back(ct);
     d.loc_conv_t = ct;
   }
+  m->steps = nullptr;
+  if (mem_dim <= 512) {
+    T1StepWeights sw{};
+    sw.pre_w0 = d.pre_w0, sw.pre_b0 = d.pre_b0, sw.pre_w1 = d.pre_w1, sw.pre_b1 = d.pre_b1;
+    sw.att_w_ih = d.att_w_ih, sw.att_w_hh = d.att_w_hh, sw.att_b_ih = d.att_b_ih, sw.att_b_hh = d.att_b_hh;
+    sw.loc_conv_w = w->loc_conv_w, sw.loc_lin_w = d.loc_lin_w, sw.loc_lin_b = d.loc_lin_b;
+    sw.query_w = d.query_w, sw.query_b = d.query_b, sw.v_w = d.v_w, sw.pd_w = d.pd_w, sw.pd_b = d.pd_b;
+    for (int l = 0; l < 2; ++l) {
+      sw.rnn_w_ih[l] = d.rnn_w_ih[l], sw.rnn_w_hh[l] = d.rnn_w_hh[l];
+      sw.rnn_b_ih[l] = d.rnn_b_ih[l], sw.rnn_b_hh[l] = d.rnn_b_hh[l];
+    }
+    sw.mel_w = d.mel_w, sw.mel_b = d.mel_b, sw.stop_w = d.stop_w, sw.stop_b = d.stop_b;
+    sw.att_init = d.att_init, sw.mem_init = d.mem_init, sw.rnn_inits = d.rnn_inits;
+    sw.mem_dim = mem_dim, sw.odim = odim;
+    if ((rc = t1_steps_create(&sw, st, &m->steps))) return rc;
+  }
   TTSX_HIP(hipStreamSynchronize(st));
   *out = m;
   return TTSX_OK;
@@ -614,6 +632,7 @@ extern "C" int ttsx_t1_destroy(ttsx_t1* m) {
   convmfma::layer_destroy(&m->last);
   cbhg_destroy(&m->enc_cbhg);
   cbhg_destroy(&m->post_cbhg);
+  t1_steps_destroy(m->steps);
   for (float* p : m->owned) (void)hipFree(p);
   float* bufs[] = {m->ws_a, m->ws_b, m->ws_annot, m->post_out};
   for (float* b : bufs)
@@ -659,6 +678,12 @@ extern "C" int ttsx_t1_decoder_run(ttsx_t1* m, const float* enc, const int32_t* 
   // processed annotations, once per utterance (LocationSensitiveAttention caches them, :82-83)
   int rc = convmfma::layer_run(m->annot, enc, ENC_D, m->ws_annot, ATT_D, 0, nullptr, 0, nullptr, B, T, st);
   if (rc) return rc;
+  // Default: eight launches per step over the whole chip.  TTSX_T1_PERSISTENT=1 (or a memory queue longer
+  // than 512 floats): the whole loop of an utterance in one workgroup.
+  const char* pers = getenv("TTSX_T1_PERSISTENT");
+  if (m->steps && !(pers && pers[0] == '1'))
+    return t1_steps_run(m->steps, enc, m->ws_annot, lengths, B, T, max_decoder_steps, mel, align, stop, n_steps,
+                        steps_run_host, st);
   DecP d = m->dec;
   d.enc = enc, d.annot = m->ws_annot, d.mel = mel, d.align = align, d.stop = stop, d.n_steps = n_steps;
   d.T = T, d.max_steps = max_decoder_steps, d.enc_len = lengths;

@@ -56,6 +56,8 @@ struct RunCtx {
   int all_done;  // every utterance has emitted its stop frame (free-running mode)
   int n_done;
   int B, T, r, free_running;
+  int max_steps;  // Tacotron (v1) stop rule: max_decoder_steps
+  int mask_finished;  // output rows of an utterance whose n_steps is already set are left unwritten
   float threshold;
   int mel_rows, align_rows, stop_rows;
   float* mel;        // [B, mel_rows, 80]
@@ -87,7 +89,7 @@ __global__ void pack_rows_kernel(float* __restrict__ dst, const float* __restric
   float v = 0.f;
   if (row < rows) {
     if (k < k1) v = w1[(size_t)row * k1 + k];
-    else if (k - k1 < k2) v = w2[(size_t)row * k2 + (k - k1)];
+    else if (w2 && k - k1 < k2) v = w2[(size_t)row * k2 + (k - k1)];  // (null w2: zero padding of K)
   }
   dst[i] = v;
 }
@@ -175,7 +177,7 @@ struct Seg {
   int kgroups;        // K of the segment / 16
 };
 
-enum { MODE_LINEAR = 0, MODE_LSTM = 1, MODE_PROJ = 2, MODE_PARTIAL = 3 };
+enum { MODE_LINEAR = 0, MODE_LSTM = 1, MODE_PROJ = 2, MODE_PARTIAL = 3, MODE_GRU = 4, MODE_MEL = 5 };
 
 // Everything a launch needs before its arithmetic is a kernel argument (no pointer is fetched
 // from device memory first), so that all global loads of a workgroup - weights, activations and
@@ -200,6 +202,14 @@ struct GemmP {
   float* out[2];  // LINEAR/PROJ: out[0] quad layout; LSTM: h ping-pong pair, written at parity^1
   float* c;       // LSTM cell state, quad layout
   float* x1;      // PROJ: prenet layer-1 activations for the next step, quad layout
+  // GRU (Tacotron v1; rows of a hidden unit = r, z, n_input, n_hidden over K = [x; h]): h ping-pong in
+  // `out` like the LSTM; with `resid` the launch also writes sum_out = h_new + resid (residual GRU stack)
+  const float* resid;
+  float* sum_out;
+  // MEL (Tacotron v1 proj_to_mel): sigmoid frames to out[0], to the run's mel rows and to the tail of the
+  // next memory queue (quads mem_keep .. mem_keep + o_quads - 1 of mem_new)
+  float* mem_new;
+  int mem_keep;
   int relu;       // LINEAR: apply ReLU
   int o_quads;    // PROJ: number of quads that are mel rows (80*r_init/4)
   // LSTM (attention LSTM only): the workgroup also leaves its share of the query projection,
@@ -225,6 +235,11 @@ __device__ __forceinline__ Pre prefetch_quad(const GemmP& p, int quad, int b) {
     r.c = p.c[qidx(quad, b, p.Bpad)];
     const int gp = p.gates_pitch ? p.gates_pitch : p.Bpad;
     if (p.gates) r.gates = reinterpret_cast<const float4*>(p.gates)[(size_t)quad * gp + p.gates_col0 + b];
+  }
+  if (MODE == MODE_GRU) {
+    const float* h_in = p.parity ? p.out[1] : p.out[0];  // the state before this step
+    r.c = h_in[qidx(quad, b, p.Bpad)];
+    if (p.resid) r.gates.x = p.resid[qidx(quad, b, p.Bpad)];
   }
   return r;
 }
@@ -255,6 +270,27 @@ __device__ __forceinline__ float epilogue_quad(const GemmP& p, int quad, int b, 
     float* h_out = p.parity ? p.out[0] : p.out[1];
     h_out[idx] = h_new;
     return h_new;
+  } else if (MODE == MODE_GRU) {
+    // torch.nn.GRUCell: r = s(W_ir x + W_hr h + b), z likewise, n = tanh(W_in x + b_in + r (W_hn h + b_hn))
+    const size_t idx = qidx(quad, b, Bpad);
+    const float rg = sigmoidf_(v[0]), zg = sigmoidf_(v[1]);
+    const float ng = tanhf(v[2] + rg * v[3]);
+    const float h_new = (1.f - zg) * ng + zg * pre.c;
+    float* h_out = p.parity ? p.out[0] : p.out[1];
+    h_out[idx] = h_new;
+    if (p.sum_out) p.sum_out[idx] = h_new + pre.gates.x;
+    return h_new;
+  } else if (MODE == MODE_MEL) {
+    RunCtx* cx = p.ctx;
+    if (quad < p.o_quads) {
+      const float4 o = make_float4(sigmoidf_(v[0]), sigmoidf_(v[1]), sigmoidf_(v[2]), sigmoidf_(v[3]));
+      reinterpret_cast<float4*>(p.out[0])[(size_t)quad * Bpad + b] = o;
+      reinterpret_cast<float4*>(p.mem_new)[(size_t)(p.mem_keep + quad) * Bpad + b] = o;
+      if (b < cx->B && !(cx->mask_finished && cx->n_steps[b] != 0)) {
+        const int row0 = (cx->out_base + p.step_in_chunk) * cx->r;
+        *reinterpret_cast<float4*>(cx->mel + ((size_t)b * cx->mel_rows + row0) * MEL_DIM + quad * 4) = o;
+      }
+    }
   } else if (MODE == MODE_LINEAR) {
     if (p.relu) v = (f32x4){fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
     reinterpret_cast<float4*>(p.out[0])[(size_t)quad * Bpad + b] = make_float4(v[0], v[1], v[2], v[3]);
@@ -342,7 +378,7 @@ struct GemmOp {
     // query-projection share: thread (d = tid & 127, cg = tid >> 7) covers columns cg*4*NT .. +4*NT-1
     constexpr int QU = 4 * R, QC = 4 * NT;
     float wq[QU];
-    const bool qshare = MODE == MODE_LSTM && p.qpart != nullptr;
+    const bool qshare = (MODE == MODE_LSTM || MODE == MODE_GRU) && p.qpart != nullptr;
     if (qshare) {
 #pragma unroll
       for (int j = 0; j < QU; ++j) wq[j] = p.wq_t[(size_t)(rb * 4 + j) * ATT_DIM + (threadIdx.x & (ATT_DIM - 1))];
@@ -398,7 +434,7 @@ struct GemmOp {
 #pragma unroll
       for (int w = 1; w < GEMM_WAVES; ++w) v += red[w][t][lane];
       const float h = epilogue_quad<MODE>(p, (rb + t / NT) * 4 + (lane >> 4), b0 + (t % NT) * 16 + (lane & 15), v, pre[k]);
-      if (MODE == MODE_LSTM) s_h[(t / NT) * 4 + (lane >> 4)][(t % NT) * 16 + (lane & 15)] = h;
+      if (MODE == MODE_LSTM || MODE == MODE_GRU) s_h[(t / NT) * 4 + (lane >> 4)][(t % NT) * 16 + (lane & 15)] = h;
     }
     if (qshare) {
       __syncthreads();
@@ -446,7 +482,7 @@ struct GemvOp {
         }
       }
     }
-    const bool qshare = MODE == MODE_LSTM && p.qpart != nullptr;
+    const bool qshare = (MODE == MODE_LSTM || MODE == MODE_GRU) && p.qpart != nullptr;
     float wq[4];
     if (qshare && tid < ATT_DIM * NB) {
 #pragma unroll
@@ -491,7 +527,7 @@ struct GemvOp {
         v[j] = t;
       }
       const float h = epilogue_quad<MODE>(p, quad_e, eb, v, pre);
-      if (MODE == MODE_LSTM) s_hq[qi][eb] = h;
+      if (MODE == MODE_LSTM || MODE == MODE_GRU) s_hq[qi][eb] = h;
     }
     if (qshare) {
       __syncthreads();
@@ -538,6 +574,7 @@ struct AttnP {
   int step_in_chunk, Bpad, norm, T;
   int gx;  // workgroups per utterance: workgroup id = b * gx + x
   // fused kernel (FusedAttnOp) only
+  const float* q_bias;  // [128] constant added to the query (Tacotron v1: query + location-linear biases), or null
   const float* qpart;   // [n_qgroups][Bpad][128] shares of the query projection left by the attention LSTM
   int n_qgroups;
   const float* wlc_p;   // [2][16][64]  location_conv weight as MFMA A-operand fragments
@@ -1004,7 +1041,7 @@ struct GravesOp {
   }
 };
 
-// The whole attention of one utterance in ONE workgroup, for encoder lengths up to 256: query (sum of
+// The whole attention of one utterance in ONE workgroup, for encoder lengths up to 512: query (sum of
 // the shares the attention LSTM left), location features, energies, normalisation, alignment
 // outputs, context.  It replaces three launches of the serial chain (query, energies, context).
 // The two contractions run on the matrix cores, one wave per tile of 16 encoder positions:
@@ -1012,7 +1049,8 @@ struct GravesOp {
 //               operand read straight from the zero-padded alignment rows in LDS  (32 MFMAs / tile)
 //   loc[d][t] = sum_f W_ld[d][f] cf[f][t]                                            (64 MFMAs / tile)
 // with the weights staged in LDS as A-operand fragments and cf handed from the first product to the
-// second through a wave-private LDS tile.  NTT = tiles per wave (1: T <= 128, 2: T <= 256).
+// second through a wave-private LDS tile.  NTT = tiles per wave (T <= 128 NTT); EDIM = encoder width
+// (512 Tacotron2, 256 Tacotron).
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a workgroup fence, which
 // waits for every outstanding global load as well - including loads issued early on purpose.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -1024,9 +1062,9 @@ __device__ long long g_fa_t[8];
 #else
 #define FA_MARK(i) do { } while (0)
 #endif
-constexpr int FA_TMAX = 256, FA_CF_PITCH = 36, FA_SA_LEN = 304;
-constexpr int FA_LDS_FLOATS = 2048 + 4096 + 2 * FA_SA_LEN + GEMM_WAVES * 16 * FA_CF_PITCH + 512 + 128 + 128 + 256 + 256;
-template <int NTT>
+constexpr int FA_TMAX = 512, FA_CF_PITCH = 36, FA_SA_LEN = FA_TMAX + 48;
+constexpr int FA_LDS_FLOATS = 2048 + 4096 + 2 * FA_SA_LEN + GEMM_WAVES * 16 * FA_CF_PITCH + 512 + 128 + 128 + 2 * FA_TMAX;
+template <int NTT, int EDIM>
 struct FusedAttnOp {
   typedef AttnP P;
   static __device__ __forceinline__ void run(const AttnP& p, int wg) {
@@ -1042,8 +1080,8 @@ struct FusedAttnOp {
     float* s_q4 = s_cf + GEMM_WAVES * 16 * FA_CF_PITCH;  // (spare)
     float* s_q = s_q4 + 512;                   // [128]
     float* s_v = s_q + 128;                    // [128]
-    float* s_e = s_v + 128;                    // [256]
-    float* s_al = s_e + 256;                   // [256]
+    float* s_e = s_v + 128;                    // [FA_TMAX]
+    float* s_al = s_e + FA_TMAX;               // [FA_TMAX]
     __shared__ float s_red[CTX_THREADS / 64];
     FA_MARK(0);
 
@@ -1067,9 +1105,10 @@ struct FusedAttnOp {
     const float4 w0 = reinterpret_cast<const float4*>(p.wlc_p)[tid];
     const float4 w1 = reinterpret_cast<const float4*>(p.wld_p)[tid];
     const float4 w2 = reinterpret_cast<const float4*>(p.wld_p)[tid + 512];
-    float sa[2];
+    constexpr int SA_U = (2 * FA_SA_LEN + CTX_THREADS - 1) / CTX_THREADS;
+    float sa[SA_U];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < SA_U; ++u) {
       const int i = tid + u * CTX_THREADS;
       const int c = i >= FA_SA_LEN ? 1 : 0, t = i - c * FA_SA_LEN - ATT_PAD;
       const float* src = c ? p.a_cum : p.a_prev;
@@ -1091,8 +1130,9 @@ struct FusedAttnOp {
     reinterpret_cast<float4*>(s_wlc)[tid] = w0;
     reinterpret_cast<float4*>(s_wld)[tid] = w1;
     reinterpret_cast<float4*>(s_wld)[tid + 512] = w2;
-    s_a[tid] = sa[0];
-    if (tid + CTX_THREADS < 2 * FA_SA_LEN) s_a[tid + CTX_THREADS] = sa[1];
+#pragma unroll
+    for (int u = 0; u < SA_U; ++u)
+      if (tid + u * CTX_THREADS < 2 * FA_SA_LEN) s_a[tid + u * CTX_THREADS] = sa[u];
     if (tid < ATT_DIM) s_v[tid] = vw;
     __syncthreads();
     FA_MARK(1);
@@ -1100,19 +1140,19 @@ struct FusedAttnOp {
     // workgroup per CU: the register file is otherwise idle), so the context costs no memory round
     // trip at the end.  Not earlier: vector loads return in order and the barrier above would have
     // waited for these 256 KB as well (measured: 4.3 us instead of 2.1 us to reach it).
-    constexpr int LPR = ENC_DIM / 4, RG = CTX_THREADS / LPR;
+    constexpr int LPR = EDIM / 4, RG = CTX_THREADS / LPR;
     const int cl = tid % LPR, rg = tid / LPR;
-    const float4* e4 = reinterpret_cast<const float4*>(p.enc + (size_t)b * T * ENC_DIM) + cl;
-    constexpr int FA_PRE = NTT == 1 ? 32 : 16;  // (two tiles per wave leave fewer registers free)
+    const float4* e4 = reinterpret_cast<const float4*>(p.enc + (size_t)b * T * EDIM) + cl;
+    constexpr int FA_PRE = NTT == 1 ? 128 / RG : 16;  // (more tiles per wave leave fewer registers free)
     float4 pre[FA_PRE];
     const int t_last = max(len - 1, 0);
 #pragma unroll
-    for (int i = 0; i < FA_PRE; ++i) pre[i] = e4[(size_t)min(rg + i * RG, t_last) * (ENC_DIM / 4)];  // (masked at use)
+    for (int i = 0; i < FA_PRE; ++i) pre[i] = e4[(size_t)min(rg + i * RG, t_last) * (EDIM / 4)];  // (masked at use)
     if (tid < ATT_DIM) {
       float acc = 0.f;
 #pragma unroll
       for (int r = 0; r < QROWS; ++r) acc += s_cf[r * ATT_DIM + tid];
-      s_q[tid] = acc;
+      s_q[tid] = acc + (p.q_bias ? p.q_bias[tid] : 0.f);
     }
     lds_barrier();  // (the encoder-row loads stay in flight)
     FA_MARK(2);
@@ -1188,7 +1228,7 @@ struct FusedAttnOp {
       const int row = cx->out_base + p.step_in_chunk;
       p.a_prev[(size_t)b * T + tid] = a;
       p.a_cum[(size_t)b * T + tid] = s_a[FA_SA_LEN + ATT_PAD + tid] + a;
-      cx->align[((size_t)b * cx->align_rows + row) * T + tid] = a;
+      if (!(cx->mask_finished && cx->n_steps[b] != 0)) cx->align[((size_t)b * cx->align_rows + row) * T + tid] = a;
     }
     // ---- context
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1201,10 +1241,10 @@ struct FusedAttnOp {
     if (NTT > 1) {
       // the remaining positions, in batches of independent row loads
 #pragma unroll 1
-      for (int base = FA_PRE; base < FA_TMAX / RG; base += FA_PRE) {
+      for (int base = FA_PRE; base < 128 * NTT / RG; base += FA_PRE) {
         if (base * RG >= len) break;
 #pragma unroll
-        for (int i = 0; i < FA_PRE; ++i) pre[i] = e4[(size_t)min(rg + (base + i) * RG, t_last) * (ENC_DIM / 4)];
+        for (int i = 0; i < FA_PRE; ++i) pre[i] = e4[(size_t)min(rg + (base + i) * RG, t_last) * (EDIM / 4)];
 #pragma unroll
         for (int i = 0; i < FA_PRE; ++i) {
           const int t = rg + (base + i) * RG;
@@ -1285,7 +1325,7 @@ __global__ void transpose_loc_kernel(float* __restrict__ conv_t, float* __restri
 // and the query weight transposed, wq_t[u][d] = W_q[d][u].
 __global__ void pack_attn_frag_kernel(float* __restrict__ wlc_p, float* __restrict__ wld_p, float* __restrict__ wq_t,
                                       const float* __restrict__ conv_w, const float* __restrict__ dense_w,
-                                      const float* __restrict__ query_w) {
+                                      const float* __restrict__ query_w, int query_dim) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < 2 * 16 * 64) {
     const int l = i & 63, kk = (i >> 6) & 15, ft = i >> 10;
@@ -1297,9 +1337,9 @@ __global__ void pack_attn_frag_kernel(float* __restrict__ wlc_p, float* __restri
     const int k = 16 * (kk >> 2) + 4 * (l >> 4) + (kk & 3), dd = 16 * dt + (l & 15);
     wld_p[i] = dense_w ? dense_w[dd * LOC_F + k] : 0.f;
   }
-  if (i < QUERY_DIM * ATT_DIM) {
+  if (i < query_dim * ATT_DIM) {
     const int u = i / ATT_DIM, dd = i % ATT_DIM;
-    wq_t[i] = query_w[(size_t)dd * QUERY_DIM + u];
+    wq_t[i] = query_w[(size_t)dd * query_dim + u];
   }
 }
 
@@ -1665,8 +1705,8 @@ hipError_t set_fused_lds_for() {
                              hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 hipError_t set_fused_lds() {
-  hipError_t e = set_fused_lds_for<FusedAttnOp<1>>();
-  return e != hipSuccess ? e : set_fused_lds_for<FusedAttnOp<2>>();
+  hipError_t e = set_fused_lds_for<FusedAttnOp<1, ENC_DIM>>();
+  return e != hipSuccess ? e : set_fused_lds_for<FusedAttnOp<2, ENC_DIM>>();
 }
 
 // Early columns of the attention LSTM, [ctx(t-1); h_a(t-1)] -> g_a, for the step with chunk index i.
@@ -1761,8 +1801,8 @@ int enqueue_step(ttsx_t2_decoder* d, int i, bool first, bool more, hipStream_t s
     pc = Piece{pd.g, split};
     pc.g.rb0 = 0, pc.g.nrb = pd.total_rb;
     const size_t smem = sizeof(float) * FA_LDS_FLOATS;
-    if (T <= 128) rc = launch_with_piece<FusedAttnOp<1>, PK2>(d, ap, B, smem, &pc, st);
-    else rc = launch_with_piece<FusedAttnOp<2>, PK2>(d, ap, B, smem, &pc, st);
+    if (T <= 128) rc = launch_with_piece<FusedAttnOp<1, ENC_DIM>, PK2>(d, ap, B, smem, &pc, st);
+    else rc = launch_with_piece<FusedAttnOp<2, ENC_DIM>, PK2>(d, ap, B, smem, &pc, st);
     if (rc) return rc;
   } else {
   // query projection   (+ first third of the decoder partial)
@@ -1936,7 +1976,7 @@ extern "C" int ttsx_t2_decoder_create(const ttsx_t2_decoder_weights* w, int r_in
         dev_alloc(&d->wq_t, (size_t)QUERY_DIM * ATT_DIM))
       return TTSX_ERR_HIP;
     pack_attn_frag_kernel<<<ceil_div(QUERY_DIM * ATT_DIM, 256), 256, 0, st>>>(
-        d->wlc_p, d->wld_p, d->wq_t, w->loc_conv_w, w->loc_conv_w ? w->loc_dense_w : nullptr, w->query_w);
+        d->wlc_p, d->wld_p, d->wq_t, w->loc_conv_w, w->loc_conv_w ? w->loc_dense_w : nullptr, w->query_w, QUERY_DIM);
     TTSX_LAUNCH_CHECK();
     TTSX_HIP(set_fused_lds());
   }
@@ -2063,7 +2103,7 @@ extern "C" int ttsx_t2_decoder_begin(ttsx_t2_decoder* d, const float* enc, const
     // B=128 79.4 / 87.0, B=64 T=256 58.3 / 62.9; at B=1 it is a tie (32.8 / 33.0): the kernel moves
     // ~260 KB through ONE CU's vector memory pipe and that costs what the two saved launches did.
     const char* f = getenv("TTSX_FUSED_ATTN");
-    d->fused = T <= FA_TMAX && !d->variant && !graves && !(f && f[0] == '0') &&
+    d->fused = T <= 256 && !d->variant && !graves && !(f && f[0] == '0') &&
                (B > GEMV_MAX_B || (f && f[0] == '1'));
   }
   d->parity0 = 0;
@@ -2455,3 +2495,458 @@ extern "C" int ttsx_debug_fa_timing(long long* out_host) {
   return TTSX_OK;
 }
 #endif
+
+// ====================================================================== Tacotron (v1) decoder steps
+// Decoder.forward in eval mode (Tacotron/TTS/models.py:558-645) with AttentionRNNCell (:124-156),
+// LocationSensitiveAttention (:71-88), Prenet (:250-253) and StopNet (:663-667) as a chain of eight
+// launches per step on the row-block engine:
+//   prenet-1 (+ the stop rule of the previous step as a side op) | prenet-2 | attention GRU (+ query
+//   shares) | fused attention | project_to_decoder_in | GRU 1 (+ residual) | GRU 2 (+ residual) |
+//   proj_to_mel + sigmoid (+ the memory-queue shift as a side op)
+// A GRU cell fits the engine's four-rows-per-hidden-unit layout as rows (r, z, n_input, n_hidden) over
+// K = [x; h], the two n rows zero-padded over the half they do not see.  All biases of the energy
+// (query, annotation, location-linear) are constants of the step and are added once (P carries the
+// annotation bias, q_bias the other two).
+#include "t1_steps.h"
+
+namespace {
+
+constexpr int T1_ENC = 256, T1_RNN = 256, T1_PRE0 = 256, T1_PRE1 = 128;
+
+// rows (r, z, n_i, n_h) of every hidden unit over K = [x (kx); h (kh)], source row order
+// g * H + u  (g = 0..3) so that pack_rows_kernel's unit interleave applies; biases likewise
+__global__ void gru_expand_kernel(float* __restrict__ w4, float* __restrict__ b4, const float* __restrict__ w_ih,
+                                  const float* __restrict__ w_hh, const float* __restrict__ b_ih,
+                                  const float* __restrict__ b_hh, int H, int kx, int kh) {
+  const int K = kx + kh;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < (size_t)4 * H) {
+    const int g = (int)(i / H), u = (int)(i % H);
+    b4[i] = g == 0 ? b_ih[u] + b_hh[u] : g == 1 ? b_ih[H + u] + b_hh[H + u] : g == 2 ? b_ih[2 * H + u] : b_hh[2 * H + u];
+  }
+  if (i >= (size_t)4 * H * K) return;
+  const int row = (int)(i / K), k = (int)(i % K), g = row / H, u = row % H;
+  float v = 0.f;
+  if (k < kx) {
+    if (g <= 2) v = w_ih[(size_t)(g * H + u) * kx + k];
+  } else {
+    if (g <= 1) v = w_hh[(size_t)(g * H + u) * kh + (k - kx)];
+    else if (g == 3) v = w_hh[(size_t)(2 * H + u) * kh + (k - kx)];
+  }
+  w4[i] = v;
+}
+
+// the part of the memory queue that survives a step: quads [drop, drop + n) of the old queue -> [0, n)
+struct MemShiftOp {
+  struct P {
+    const float4* src;
+    float4* dst;
+    int n;  // float4 elements
+    RunCtx* ctx;
+  };
+  static __device__ __forceinline__ void run(const P& p, int wg) {
+    if (p.ctx->all_done) return;
+    for (int i = wg * GEMM_THREADS + threadIdx.x; i < p.n; i += 4 * GEMM_THREADS) p.dst[i] = p.src[i];
+  }
+};
+
+// stop token and stop rule of step `idx` of the chunk (:624-640): stop = sigmoid(w . [d; out] + b);
+// the utterance ends after step t (1-based) when t > T/4 and (stop > 0.6 or the attention on its last
+// position > 0.6), or when t > max_decoder_steps.  One workgroup; a wave per utterance.
+struct T1StopOp {
+  struct P {
+    const float* d2;      // quad [256]
+    const float* out;     // quad [odim]
+    const float* stop_w;  // [256 + odim]
+    const float* stop_b;
+    const float* a_prev;  // [B][T]
+    const int32_t* len;
+    RunCtx* ctx;
+    int idx, Bpad, odim;
+  };
+  static __device__ __forceinline__ void run(const P& p, int) {
+    RunCtx* cx = p.ctx;
+    if (cx->all_done) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int b = wave; b < cx->B; b += GEMM_WAVES) {
+      float acc = 0.f;
+      for (int k = lane; k < T1_RNN + p.odim; k += 64)
+        acc += p.stop_w[k] * (k < T1_RNN ? p.d2[qidx(k, b, p.Bpad)] : p.out[qidx(k - T1_RNN, b, p.Bpad)]);
+      acc = wave_sum(acc);
+      if (lane == 0 && cx->n_steps[b] == 0) {
+        const float s = sigmoidf_(acc + p.stop_b[0]);
+        cx->stop[(size_t)b * cx->stop_rows + cx->out_base + p.idx] = s;
+        const int tn = cx->base + p.idx + 1, len = p.len[b];
+        const bool end = ((float)tn > (float)len / 4.f && (s > 0.6f || p.a_prev[(size_t)b * cx->T + len - 1] > 0.6f)) ||
+                         tn > cx->max_steps;
+        if (end && cx->n_steps[b] == 0) {
+          cx->n_steps[b] = tn;
+          if (atomicAdd(&cx->n_done, 1) + 1 == cx->B) cx->all_done = 1;
+        }
+      }
+    }
+  }
+};
+
+__global__ void t1_init_state_kernel(float* __restrict__ mem, float* __restrict__ h_att, float* __restrict__ h_d1,
+                                     float* __restrict__ h_d2, const float* __restrict__ mem_init,
+                                     const float* __restrict__ att_init, const float* __restrict__ rnn_inits,
+                                     int mem_dim, int Bpad) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < mem_dim * Bpad) mem[qidx(i / Bpad, i % Bpad, Bpad)] = mem_init[i / Bpad];
+  if (i < T1_RNN * Bpad) {
+    const int u = i / Bpad, b = i % Bpad;
+    h_att[qidx(u, b, Bpad)] = att_init[u];
+    h_d1[qidx(u, b, Bpad)] = rnn_inits[u];
+    h_d2[qidx(u, b, Bpad)] = rnn_inits[T1_RNN + u];
+  }
+}
+
+__global__ void t1_len_kernel(int32_t* __restrict__ dst, const int32_t* __restrict__ src, int B, int T) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B) dst[b] = src ? min(max(src[b], 1), T) : T;
+}
+
+__global__ void t1_qbias_kernel(float* __restrict__ qb, const float* __restrict__ query_b,
+                                const float* __restrict__ loc_lin_b) {
+  const int i = threadIdx.x;
+  if (i < ATT_DIM) qb[i] = query_b[i] + loc_lin_b[i];
+}
+
+}  // namespace
+
+struct t1_steps {
+  int mem_dim, odim, mem_k;  // mem_k: mem_dim rounded up to 128 (the engine's K granularity)
+  float *w_pre0, *b_pre0, *w_pre1, *b_pre1, *w_att, *b_att, *w_pd, *b_pd, *w_g1, *b_g1, *w_g2, *b_g2, *w_mel, *b_mel;
+  float *wq_t, *wlc_p, *wld_p, *q_bias, *v_w, *zero1, *stop_w, *stop_b;
+  const float *mem_init, *att_init, *rnn_inits;  // borrowed from the owner of the handle
+  // workspace
+  int cap_B, cap_T, Bpad;
+  float *mem[2], *x1, *x2, *h_att[2], *ctx, *d0, *h_d1[2], *d1, *h_d2[2], *d2, *out, *qpart, *a_prev, *a_cum, *enc_ws, *P_ws;
+  int32_t* len_ws;
+  RunCtx *rc, *rc_host;
+  int* host_flag;
+  hipGraphExec_t graph;
+  hipStream_t cap_stream;
+  int g_B, g_T, g_gen, ws_gen;
+};
+
+namespace {
+
+template <int MODE, int KGW, class Side>
+int t1_launch(const t1_steps* s, int B, GemmP g, int nrb, const typename Side::P& side, int n_side, hipStream_t st) {
+  g.rb0 = 0, g.nrb = nrb;
+  if (B == 1) {
+    dual_kernel<GemvOp<1, KGW, MODE>, Side><<<nrb + n_side, GEMM_THREADS, 0, st>>>(g, side, nrb);
+  } else if (B == 2) {
+    dual_kernel<GemvOp<2, KGW, MODE>, Side><<<nrb + n_side, GEMM_THREADS, 0, st>>>(g, side, nrb);
+  } else {
+    const int n = nrb * (s->Bpad / 16);
+    dual_kernel<GemmOp<1, 1, KGW, MODE>, Side><<<n + n_side, GEMM_THREADS, 0, st>>>(g, side, n);
+  }
+  TTSX_LAUNCH_CHECK();
+  return TTSX_OK;
+}
+
+T1StopOp::P t1_stop_params(const t1_steps* s, int idx) {
+  T1StopOp::P q{};
+  q.d2 = s->d2, q.out = s->out, q.stop_w = s->stop_w, q.stop_b = s->stop_b, q.a_prev = s->a_prev, q.len = s->len_ws;
+  q.ctx = s->rc, q.idx = idx, q.Bpad = s->Bpad, q.odim = s->odim;
+  return q;
+}
+
+// One decoder step (index i of the chunk; `parity` = steps completed before it, & 1).
+int t1_enqueue_step(t1_steps* s, int B, int T, int i, int parity, hipStream_t st) {
+  const int Bpad = s->Bpad;
+  int rc;
+  GemmP g{};
+  g.Bpad = Bpad, g.ctx = s->rc, g.step_in_chunk = i, g.parity = parity;
+  // prenet layer 1 on the memory queue   (+ stop rule of the previous step)
+  g.Wp = s->w_pre0, g.bias = s->b_pre0, g.nseg = 1, g.KG = s->mem_k / 16, g.kg0 = 0, g.kg_stride = g.KG;
+  g.seg[0] = Seg{{s->mem[0], s->mem[1]}, 1, s->mem_k / 16};
+  g.out[0] = s->x1, g.relu = 1;
+  {
+    const T1StopOp::P sp = t1_stop_params(s, i - 1);
+    const int n_side = i > 0 ? 1 : 0;
+    if (s->mem_k == 512) rc = t1_launch<MODE_LINEAR, 4, T1StopOp>(s, B, g, T1_PRE0 / 16, sp, n_side, st);
+    else if (s->mem_k == 256) rc = t1_launch<MODE_LINEAR, 2, T1StopOp>(s, B, g, T1_PRE0 / 16, sp, n_side, st);
+    else if (s->mem_k == 384) rc = t1_launch<MODE_LINEAR, 3, T1StopOp>(s, B, g, T1_PRE0 / 16, sp, n_side, st);
+    else rc = t1_launch<MODE_LINEAR, 1, T1StopOp>(s, B, g, T1_PRE0 / 16, sp, n_side, st);
+    if (rc) return rc;
+  }
+  // prenet layer 2
+  g.Wp = s->w_pre1, g.bias = s->b_pre1, g.KG = T1_PRE0 / 16, g.kg_stride = g.KG;
+  g.seg[0] = Seg{{s->x1, nullptr}, 0, T1_PRE0 / 16};
+  g.out[0] = s->x2;
+  if ((rc = t1_launch<MODE_LINEAR, 2, NoOp>(s, B, g, T1_PRE1 / 16, 0, 0, st))) return rc;
+  // attention GRU on [prenet; context], leaving the shares of the query projection
+  g.Wp = s->w_att, g.bias = s->b_att, g.nseg = 3, g.KG = (T1_PRE1 + T1_ENC + T1_RNN) / 16, g.kg_stride = g.KG;
+  g.seg[0] = Seg{{s->x2, nullptr}, 0, T1_PRE1 / 16};
+  g.seg[1] = Seg{{s->ctx, nullptr}, 0, T1_ENC / 16};
+  g.seg[2] = Seg{{s->h_att[0], s->h_att[1]}, 1, T1_RNN / 16};
+  g.out[0] = s->h_att[0], g.out[1] = s->h_att[1], g.relu = 0;
+  g.wq_t = s->wq_t, g.qpart = s->qpart;
+  if ((rc = t1_launch<MODE_GRU, 5, NoOp>(s, B, g, T1_RNN / 4, 0, 0, st))) return rc;
+  g.wq_t = nullptr, g.qpart = nullptr;
+  // attention
+  {
+    AttnP ap{};
+    ap.P = s->P_ws, ap.v_w = s->v_w, ap.v_b = s->zero1, ap.a_prev = s->a_prev, ap.a_cum = s->a_cum;
+    ap.ctx_out = s->ctx, ap.enc = s->enc_ws, ap.len = s->len_ws, ap.T = T, ap.ctx = s->rc, ap.step_in_chunk = i;
+    ap.Bpad = Bpad, ap.norm = TTSX_NORM_SIGMOID, ap.q_bias = s->q_bias, ap.qpart = s->qpart;
+    ap.n_qgroups = T1_RNN / 4, ap.wlc_p = s->wlc_p, ap.wld_p = s->wld_p;
+    const size_t smem = sizeof(float) * FA_LDS_FLOATS;
+    if (T <= 128) dual_kernel<FusedAttnOp<1, T1_ENC>, NoOp><<<B, GEMM_THREADS, smem, st>>>(ap, 0, B);
+    else if (T <= 256) dual_kernel<FusedAttnOp<2, T1_ENC>, NoOp><<<B, GEMM_THREADS, smem, st>>>(ap, 0, B);
+    else dual_kernel<FusedAttnOp<4, T1_ENC>, NoOp><<<B, GEMM_THREADS, smem, st>>>(ap, 0, B);
+    TTSX_LAUNCH_CHECK();
+  }
+  // decoder input = project_to_decoder_in([h_att; context])
+  g.Wp = s->w_pd, g.bias = s->b_pd, g.nseg = 2, g.KG = (T1_RNN + T1_ENC) / 16, g.kg_stride = g.KG;
+  g.seg[0] = Seg{{s->h_att[0], s->h_att[1]}, 2, T1_RNN / 16};
+  g.seg[1] = Seg{{s->ctx, nullptr}, 0, T1_ENC / 16};
+  g.out[0] = s->d0, g.out[1] = nullptr;
+  if ((rc = t1_launch<MODE_LINEAR, 4, NoOp>(s, B, g, T1_RNN / 16, 0, 0, st))) return rc;
+  // the two residual GRUs
+  g.nseg = 2, g.KG = 2 * T1_RNN / 16, g.kg_stride = g.KG;
+  g.Wp = s->w_g1, g.bias = s->b_g1;
+  g.seg[0] = Seg{{s->d0, nullptr}, 0, T1_RNN / 16};
+  g.seg[1] = Seg{{s->h_d1[0], s->h_d1[1]}, 1, T1_RNN / 16};
+  g.out[0] = s->h_d1[0], g.out[1] = s->h_d1[1], g.resid = s->d0, g.sum_out = s->d1;
+  if ((rc = t1_launch<MODE_GRU, 4, NoOp>(s, B, g, T1_RNN / 4, 0, 0, st))) return rc;
+  g.Wp = s->w_g2, g.bias = s->b_g2;
+  g.seg[0] = Seg{{s->d1, nullptr}, 0, T1_RNN / 16};
+  g.seg[1] = Seg{{s->h_d2[0], s->h_d2[1]}, 1, T1_RNN / 16};
+  g.out[0] = s->h_d2[0], g.out[1] = s->h_d2[1], g.resid = s->d1, g.sum_out = s->d2;
+  if ((rc = t1_launch<MODE_GRU, 4, NoOp>(s, B, g, T1_RNN / 4, 0, 0, st))) return rc;
+  g.resid = nullptr, g.sum_out = nullptr;
+  // mel frames   (+ the surviving part of the memory queue)
+  g.Wp = s->w_mel, g.bias = s->b_mel, g.nseg = 1, g.KG = T1_RNN / 16, g.kg_stride = g.KG;
+  g.seg[0] = Seg{{s->d2, nullptr}, 0, T1_RNN / 16};
+  g.out[0] = s->out, g.out[1] = nullptr, g.o_quads = s->odim / 4;
+  float* mem_old = s->mem[parity];
+  float* mem_new = s->mem[parity ^ 1];
+  const int keep_quads = (s->mem_dim - s->odim) / 4;
+  g.mem_new = mem_new, g.mem_keep = keep_quads;
+  MemShiftOp::P ms{};
+  ms.src = reinterpret_cast<const float4*>(mem_old) + (size_t)(s->odim / 4) * Bpad;
+  ms.dst = reinterpret_cast<float4*>(mem_new), ms.n = keep_quads * Bpad, ms.ctx = s->rc;
+  return t1_launch<MODE_MEL, 2, MemShiftOp>(s, B, g, ceil_div(s->odim, 16), ms, keep_quads > 0 ? 4 : 0, st);
+}
+
+int t1_enqueue_chunk(t1_steps* s, int B, int T, int n, hipStream_t st) {
+  for (int i = 0; i < n; ++i) {
+    int rc = t1_enqueue_step(s, B, T, i, i & 1, st);
+    if (rc) return rc;
+  }
+  // the stop rule of the chunk's last step, then move the chunk base
+  dual_kernel<NoOp, T1StopOp><<<1, GEMM_THREADS, 0, st>>>(0, t1_stop_params(s, n - 1), 0);
+  TTSX_LAUNCH_CHECK();
+  ctx_advance_kernel<<<1, 1, 0, st>>>(s->rc, n);
+  TTSX_LAUNCH_CHECK();
+  return TTSX_OK;
+}
+
+void t1_free_ws(t1_steps* s) {
+  float** bufs[] = {&s->mem[0], &s->mem[1], &s->x1, &s->x2, &s->h_att[0], &s->h_att[1], &s->ctx, &s->d0, &s->h_d1[0],
+                    &s->h_d1[1], &s->d1, &s->h_d2[0], &s->h_d2[1], &s->d2, &s->out, &s->qpart, &s->a_prev, &s->a_cum,
+                    &s->enc_ws, &s->P_ws};
+  for (float** b : bufs) {
+    if (*b) (void)hipFree(*b);
+    *b = nullptr;
+  }
+  if (s->len_ws) (void)hipFree(s->len_ws);
+  s->len_ws = nullptr;
+  s->cap_B = s->cap_T = 0;
+  if (s->graph) (void)hipGraphExecDestroy(s->graph);
+  s->graph = nullptr;
+}
+
+int t1_pack_gru(float** wp, float** bp, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
+                int kx, hipStream_t st) {
+  const int H = T1_RNN, K = kx + H;
+  float *w4 = nullptr, *b4 = nullptr;
+  if (dev_alloc(&w4, (size_t)4 * H * K) || dev_alloc(&b4, 4 * H)) return TTSX_ERR_HIP;
+  const size_t n = (size_t)4 * H * K;
+  gru_expand_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(w4, b4, w_ih, w_hh, b_ih, b_hh, H, kx, H);
+  TTSX_LAUNCH_CHECK();
+  int rc = pack_layer(wp, bp, w4, K, nullptr, 0, b4, nullptr, 4 * H, H, st);
+  TTSX_HIP(hipStreamSynchronize(st));
+  (void)hipFree(w4), (void)hipFree(b4);
+  return rc;
+}
+
+}  // namespace
+
+int t1_steps_create(const T1StepWeights* w, hipStream_t st, t1_steps** out) {
+  TTSX_ARG(w && out, "t1_steps_create: null argument");
+  TTSX_ARG(w->mem_dim % 4 == 0 && w->odim % 16 == 0 && w->odim <= w->mem_dim && w->mem_dim <= 512,
+           "t1_steps_create: memory %d / output %d floats not supported", w->mem_dim, w->odim);
+  t1_steps* s = new t1_steps();
+  memset(s, 0, sizeof(*s));
+  s->mem_dim = w->mem_dim, s->odim = w->odim, s->mem_k = round_up(w->mem_dim, 128);
+  s->mem_init = w->mem_init, s->att_init = w->att_init, s->rnn_inits = w->rnn_inits;
+  int rc = 0;
+  // prenet layer 1: K padded with zero columns up to the engine's granularity
+  rc |= pack_layer(&s->w_pre0, &s->b_pre0, w->pre_w0, w->mem_dim, nullptr, s->mem_k - w->mem_dim, w->pre_b0, nullptr,
+                   T1_PRE0, 0, st);
+  rc |= pack_layer(&s->w_pre1, &s->b_pre1, w->pre_w1, T1_PRE0, nullptr, 0, w->pre_b1, nullptr, T1_PRE1, 0, st);
+  rc |= t1_pack_gru(&s->w_att, &s->b_att, w->att_w_ih, w->att_w_hh, w->att_b_ih, w->att_b_hh, T1_PRE1 + T1_ENC, st);
+  rc |= pack_layer(&s->w_pd, &s->b_pd, w->pd_w, T1_RNN + T1_ENC, nullptr, 0, w->pd_b, nullptr, T1_RNN, 0, st);
+  rc |= t1_pack_gru(&s->w_g1, &s->b_g1, w->rnn_w_ih[0], w->rnn_w_hh[0], w->rnn_b_ih[0], w->rnn_b_hh[0], T1_RNN, st);
+  rc |= t1_pack_gru(&s->w_g2, &s->b_g2, w->rnn_w_ih[1], w->rnn_w_hh[1], w->rnn_b_ih[1], w->rnn_b_hh[1], T1_RNN, st);
+  rc |= pack_layer(&s->w_mel, &s->b_mel, w->mel_w, T1_RNN, nullptr, 0, w->mel_b, nullptr, w->odim, 0, st);
+  if (rc) return TTSX_ERR_HIP;
+  if (dev_alloc(&s->wlc_p, 2 * 16 * 64) || dev_alloc(&s->wld_p, 8 * 8 * 64) || dev_alloc(&s->wq_t, (size_t)QUERY_DIM * ATT_DIM) ||
+      dev_alloc(&s->q_bias, ATT_DIM) || dev_alloc(&s->zero1, 4))
+    return TTSX_ERR_HIP;
+  TTSX_HIP(hipMemsetAsync(s->wq_t, 0, sizeof(float) * QUERY_DIM * ATT_DIM, st));
+  TTSX_HIP(hipMemsetAsync(s->zero1, 0, sizeof(float) * 4, st));
+  pack_attn_frag_kernel<<<ceil_div(T1_RNN * ATT_DIM, 256), 256, 0, st>>>(s->wlc_p, s->wld_p, s->wq_t, w->loc_conv_w,
+                                                                        w->loc_lin_w, w->query_w, T1_RNN);
+  TTSX_LAUNCH_CHECK();
+  t1_qbias_kernel<<<1, ATT_DIM, 0, st>>>(s->q_bias, w->query_b, w->loc_lin_b);
+  TTSX_LAUNCH_CHECK();
+  rc |= copy_dev(&s->v_w, w->v_w, ATT_DIM, st);
+  rc |= copy_dev(&s->stop_w, w->stop_w, T1_RNN + w->odim, st);
+  rc |= copy_dev(&s->stop_b, w->stop_b, 1, st);
+  if (rc) return TTSX_ERR_HIP;
+  TTSX_HIP(hipMalloc(reinterpret_cast<void**>(&s->rc), sizeof(RunCtx)));
+  TTSX_HIP(hipHostMalloc(reinterpret_cast<void**>(&s->rc_host), sizeof(RunCtx), hipHostMallocDefault));
+  TTSX_HIP(hipHostMalloc(reinterpret_cast<void**>(&s->host_flag), 4 * sizeof(int), hipHostMallocDefault));
+  TTSX_HIP(hipStreamCreateWithFlags(&s->cap_stream, hipStreamNonBlocking));
+  {
+    const int bytes = FA_LDS_FLOATS * (int)sizeof(float);
+    TTSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dual_kernel<FusedAttnOp<1, T1_ENC>, NoOp>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    TTSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dual_kernel<FusedAttnOp<2, T1_ENC>, NoOp>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    TTSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dual_kernel<FusedAttnOp<4, T1_ENC>, NoOp>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  }
+  TTSX_HIP(hipStreamSynchronize(st));
+  *out = s;
+  return TTSX_OK;
+}
+
+void t1_steps_destroy(t1_steps* s) {
+  if (!s) return;
+  t1_free_ws(s);
+  float* bufs[] = {s->w_pre0, s->b_pre0, s->w_pre1, s->b_pre1, s->w_att, s->b_att, s->w_pd, s->b_pd, s->w_g1, s->b_g1,
+                   s->w_g2, s->b_g2, s->w_mel, s->b_mel, s->wq_t, s->wlc_p, s->wld_p, s->q_bias, s->v_w, s->zero1,
+                   s->stop_w, s->stop_b};
+  for (float* b : bufs)
+    if (b) (void)hipFree(b);
+  if (s->cap_stream) (void)hipStreamDestroy(s->cap_stream);
+  if (s->rc) (void)hipFree(s->rc);
+  if (s->rc_host) (void)hipHostFree(s->rc_host);
+  if (s->host_flag) (void)hipHostFree(s->host_flag);
+  delete s;
+}
+
+int t1_steps_run(t1_steps* s, const float* enc, const float* annot, const int32_t* lengths, int B, int T,
+                 int max_decoder_steps, float* mel, float* align, float* stop, int32_t* n_steps, int* steps_run_host,
+                 hipStream_t st) {
+  TTSX_ARG(s && enc && annot && mel && align && stop && n_steps, "t1_steps_run: null argument");
+  TTSX_ARG(B >= 1 && B <= 4096 && T >= 1 && T <= FA_TMAX, "t1_steps_run: bad shape B=%d T=%d (T <= %d)", B, T, FA_TMAX);
+  const int Bpad = B <= GEMV_MAX_B ? B : (B <= 32 ? round_up(B, 16) : round_up(B, 64));
+  if (s->cap_B != Bpad || s->cap_T < T) {
+    t1_free_ws(s);
+    const size_t cb = Bpad, ct = T;
+    int rc = 0;
+    for (int i = 0; i < 2; ++i) {
+      rc |= dev_alloc(&s->mem[i], (size_t)s->mem_k * cb);
+      rc |= dev_alloc(&s->h_att[i], T1_RNN * cb);
+      rc |= dev_alloc(&s->h_d1[i], T1_RNN * cb);
+      rc |= dev_alloc(&s->h_d2[i], T1_RNN * cb);
+    }
+    rc |= dev_alloc(&s->x1, T1_PRE0 * cb);
+    rc |= dev_alloc(&s->x2, T1_PRE1 * cb);
+    rc |= dev_alloc(&s->ctx, T1_ENC * cb);
+    rc |= dev_alloc(&s->d0, T1_RNN * cb);
+    rc |= dev_alloc(&s->d1, T1_RNN * cb);
+    rc |= dev_alloc(&s->d2, T1_RNN * cb);
+    rc |= dev_alloc(&s->out, (size_t)round_up(s->odim, 16) * cb);
+    rc |= dev_alloc(&s->qpart, (size_t)(T1_RNN / 4) * cb * ATT_DIM);
+    rc |= dev_alloc(&s->a_prev, cb * ct);
+    rc |= dev_alloc(&s->a_cum, cb * ct);
+    rc |= dev_alloc(&s->enc_ws, cb * ct * T1_ENC);
+    rc |= dev_alloc(&s->P_ws, cb * ct * ATT_DIM);
+    rc |= dev_alloc(&s->len_ws, cb);
+    if (rc) return TTSX_ERR_HIP;
+    s->cap_B = Bpad, s->cap_T = T;
+    s->ws_gen += 1;
+  }
+  s->Bpad = Bpad;
+  const size_t cb = Bpad;
+  // ---- initial state (Decoder._init_states, :538-556): learned rows, zero context and alignments
+  for (int i = 0; i < 2; ++i) {
+    TTSX_HIP(hipMemsetAsync(s->mem[i], 0, sizeof(float) * s->mem_k * cb, st));
+    TTSX_HIP(hipMemsetAsync(s->h_att[i], 0, sizeof(float) * T1_RNN * cb, st));
+    TTSX_HIP(hipMemsetAsync(s->h_d1[i], 0, sizeof(float) * T1_RNN * cb, st));
+    TTSX_HIP(hipMemsetAsync(s->h_d2[i], 0, sizeof(float) * T1_RNN * cb, st));
+  }
+  float* zero[] = {s->x1, s->x2, s->ctx, s->d0, s->d1, s->d2};
+  const size_t zn[] = {T1_PRE0 * cb, T1_PRE1 * cb, T1_ENC * cb, T1_RNN * cb, T1_RNN * cb, T1_RNN * cb};
+  for (int i = 0; i < 6; ++i) TTSX_HIP(hipMemsetAsync(zero[i], 0, sizeof(float) * zn[i], st));
+  TTSX_HIP(hipMemsetAsync(s->out, 0, sizeof(float) * (size_t)round_up(s->odim, 16) * cb, st));
+  TTSX_HIP(hipMemsetAsync(s->a_prev, 0, sizeof(float) * (size_t)B * T, st));
+  TTSX_HIP(hipMemsetAsync(s->a_cum, 0, sizeof(float) * (size_t)B * T, st));
+  t1_init_state_kernel<<<ceil_div(s->mem_k * Bpad, 256), 256, 0, st>>>(s->mem[0], s->h_att[0], s->h_d1[0], s->h_d2[0],
+                                                                     s->mem_init, s->att_init, s->rnn_inits,
+                                                                     s->mem_dim, Bpad);
+  TTSX_LAUNCH_CHECK();
+  TTSX_HIP(hipMemcpyAsync(s->enc_ws, enc, sizeof(float) * (size_t)B * T * T1_ENC, hipMemcpyDeviceToDevice, st));
+  TTSX_HIP(hipMemcpyAsync(s->P_ws, annot, sizeof(float) * (size_t)B * T * ATT_DIM, hipMemcpyDeviceToDevice, st));
+  t1_len_kernel<<<ceil_div(B, 256), 256, 0, st>>>(s->len_ws, lengths, B, T);
+  TTSX_LAUNCH_CHECK();
+  TTSX_HIP(hipMemsetAsync(n_steps, 0, sizeof(int32_t) * B, st));
+  RunCtx* h = s->rc_host;
+  memset(h, 0, sizeof(*h));
+  const int rows = max_decoder_steps + 1;
+  h->B = B, h->T = T, h->r = s->odim / MEL_DIM, h->free_running = 1, h->max_steps = max_decoder_steps;
+  h->mask_finished = 1;
+  h->mel = mel, h->mel_rows = rows * (s->odim / MEL_DIM), h->align = align, h->align_rows = rows;
+  h->stop = stop, h->stop_rows = rows, h->n_steps = n_steps;
+  TTSX_HIP(hipMemcpyAsync(s->rc, h, sizeof(RunCtx), hipMemcpyHostToDevice, st));
+  TTSX_HIP(hipStreamSynchronize(st));
+  // ---- chunks of CHUNK steps as one cached graph; the stop flag is polled once per chunk
+  int launched = 0;
+  while (launched < rows) {
+    const int n = std::min(CHUNK, rows - launched);
+    if (n == CHUNK) {
+      const bool cached = s->graph && s->g_B == B && s->g_T == T && s->g_gen == s->ws_gen;
+      if (!cached) {
+        if (s->graph) (void)hipGraphExecDestroy(s->graph);
+        s->graph = nullptr;
+        hipGraph_t graph = nullptr;
+        TTSX_HIP(hipStreamBeginCapture(s->cap_stream, hipStreamCaptureModeThreadLocal));
+        int rc = t1_enqueue_chunk(s, B, T, n, s->cap_stream);
+        hipError_t e = hipStreamEndCapture(s->cap_stream, &graph);
+        if (rc) {
+          if (graph) (void)hipGraphDestroy(graph);
+          return rc;
+        }
+        TTSX_HIP(e);
+        TTSX_HIP(hipGraphInstantiate(&s->graph, graph, nullptr, nullptr, 0));
+        (void)hipGraphDestroy(graph);
+        s->g_B = B, s->g_T = T, s->g_gen = s->ws_gen;
+      }
+      TTSX_HIP(hipGraphLaunch(s->graph, st));
+    } else {
+      int rc = t1_enqueue_chunk(s, B, T, n, st);
+      if (rc) return rc;
+    }
+    launched += n;
+    TTSX_HIP(hipMemcpyAsync(s->host_flag, &s->rc->all_done, sizeof(int), hipMemcpyDeviceToHost, st));
+    TTSX_HIP(hipStreamSynchronize(st));
+    if (s->host_flag[0]) break;
+  }
+  std::vector<int32_t> host(B);
+  TTSX_HIP(hipMemcpyAsync(host.data(), n_steps, sizeof(int32_t) * B, hipMemcpyDeviceToHost, st));
+  TTSX_HIP(hipStreamSynchronize(st));
+  int run = 0;
+  for (int b = 0; b < B; ++b) run = std::max(run, (int)host[b]);
+  if (steps_run_host) *steps_run_host = run;
+  return TTSX_OK;
+}
