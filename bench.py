@@ -120,6 +120,59 @@ def cpu_baseline(sd, T_in, sample_steps, r):
                 model_s=t1 - t0, vocoder_s=t2 - t1, wav_rms=float(np.sqrt(np.mean(wav ** 2))))
 
 
+def tacotron_v1_batch1(dev, T_in=100, steps=200):
+    """The Tacotron (CBHG postnet, linear spectrogram) configuration at batch 1: embedding -> encoder CBHG ->
+    greedy decoder -> post-CBHG + last_linear -> 60-iteration Griffin-Lim (win 1102, reflect padding)."""
+    from tts_amd import synthetic
+    from tts_amd.audio import AudioProcessor
+    from tts_amd.tacotron import Tacotron
+    sd = synthetic.t1_state_dict(seed=0, gains=dict(stop=0.0, stop_bias=-20.0, v=2.0))   # runs to max_decoder_steps
+    m = Tacotron(61, 256, 1025, 80, 2, None, 5)
+    m.load_state_dict(sd)
+    m.cuda(dev.index).eval()
+    m.decoder.max_decoder_steps = steps
+    ap = AudioProcessor(sample_rate=22050, num_mels=80, min_level_db=-100, frame_shift_ms=12.5, frame_length_ms=50,
+                        ref_level_db=20, num_freq=1025, power=1.5, preemphasis=0.98, signal_norm=True,
+                        symmetric_norm=False, max_norm=1, clip_norm=True, griffin_lim_iters=60, tacotron_v1=True,
+                        verbose=False, device=dev)
+    ids = torch.as_tensor(synthetic.t1_text_ids(7, T_in)).to(dev)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+
+    def run(record=False):
+        if record:
+            ev[0].record()
+        enc = m.encode(ids)
+        if record:
+            ev[1].record()
+        dec = m.decode(enc)
+        if record:
+            ev[2].record()
+        lin = m.postnet(dec[0])
+        if record:
+            ev[3].record()
+        ph = torch.rand(1, lin.shape[1], 1025, device=dev)
+        wav = ap.griffin_lim_batch(ap.spec_to_mag(lin, mel=False), ph)
+        if record:
+            ev[4].record()
+        return lin.shape[1], int(dec[3].max())
+
+    run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        frames, n_steps = run()
+    torch.cuda.synchronize()
+    lat = (time.perf_counter() - t0) / 3
+    run(record=True)
+    torch.cuda.synchronize()
+    st = [ev[i].elapsed_time(ev[i + 1]) for i in range(4)]
+    audio_s = frames * 275 / 22050.0
+    return {"workload": "Tacotron (v1) B=1, T_in=%d, %d decoder steps, r=2, post-CBHG + last_linear + 60-iter Griffin-Lim"
+                        % (T_in, n_steps), "latency_s": lat, "audio_s": audio_s, "real_time_factor": lat / audio_s,
+            "frames_per_s": frames / lat, "decoder_us_per_step": st[1] * 1e3 / n_steps,
+            "stage_ms": {"encoder": st[0], "decoder": st[1], "postnet": st[2], "griffin_lim": st[3]}}
+
+
 def main():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
@@ -222,6 +275,21 @@ def main():
                          "decoder_hbm_gbs": dec_step_bytes(1, 100) / (d_us * 1e-6) / 1e9,
                          "decoder_hbm_frac": dec_step_bytes(1, 100) / (d_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                          "workload": "B=1, T_in=100, %d decoder steps, r=%d" % (S, r)}
+        out["tacotron_v1_batch1"] = tacotron_v1_batch1(dev)
+        # long-form input: ~1000 symbols, 2000 decoder steps (attention over a long encoder axis)
+        idsL = torch.as_tensor(synthetic.t2_text_ids(77, 1, 1000)).to(dev)
+        wlL = Workload(model, ap, idsL, 2000, torch.rand(1, 2000 * r, 1025, device=dev))
+        wlL.run()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        wlL.run()
+        torch.cuda.synchronize()
+        latL = time.perf_counter() - t0
+        wlL.run(record=True)
+        sL = wlL.stages()
+        out["longform"] = {"workload": "B=1, T_in=1000, 2000 decoder steps, r=%d" % r, "latency_s": latL,
+                           "real_time_factor": latL / (2000 * r * 275 / 22050.0), "stage_ms": sL,
+                           "decoder_us_per_step": sL["decoder"] * 1e3 / 2000}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(sd, T, a.cpu_sample_steps, r)
     else:
