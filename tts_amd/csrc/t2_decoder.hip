@@ -170,6 +170,14 @@ __global__ void compose_proj_ext_kernel(float* __restrict__ ext_w, float* __rest
   }
 }
 
+#ifdef TTSX_FA_TIMING
+// phase timestamps of workgroup 0 (100 MHz wall clock), for tuning builds only
+__device__ long long g_fa_t[16];
+#define FA_MARK(i) do { if (wg == 0 && threadIdx.x == 0) g_fa_t[i] = wall_clock64(); } while (0)
+#else
+#define FA_MARK(i) do { } while (0)
+#endif
+
 // ------------------------------------------------------------------ GEMM / GEMV engines
 struct Seg {
   const float* x[2];  // quad-interleaved activation buffer(s)
@@ -345,11 +353,15 @@ template <int R, int NT, int KGW, int MODE>
 struct GemmOp {
   typedef GemmP P;
   static __device__ __forceinline__ void run(const GemmP& p, int wg) {
+    if (KGW == 20) FA_MARK(8);
     const int done = p.ctx->all_done;
     const int ngrp = p.nrb / R;  // row-block groups of this launch
     const int rb = p.rb0 + (wg % ngrp) * R, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int b0 = (wg / ngrp) * (NT * 16);
-    constexpr int DMAX = (R * NT >= 4) ? 4 : (NT == 1 && R == 1 ? 8 : 6);
+#ifndef TTSX_DMAX_BIG
+#define TTSX_DMAX_BIG 4
+#endif
+    constexpr int DMAX = (R * NT >= 4) ? TTSX_DMAX_BIG : (NT == 1 && R == 1 ? 8 : 6);
     constexpr int D = KGW < DMAX ? KGW : DMAX;
     constexpr int TILES = R * NT, TPW = (TILES + GEMM_WAVES - 1) / GEMM_WAVES;
     __shared__ f32x4 red[GEMM_WAVES][TILES][64];
@@ -401,15 +413,17 @@ struct GemmOp {
 #pragma unroll
     for (int i = 0; i < KGW; ++i) {
       const int sl = i % D;
-#pragma unroll
-      for (int r = 0; r < R; ++r)
-#pragma unroll
-        for (int n = 0; n < NT; ++n) {
-          acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[sl][r].x, xv[sl][n].x, acc[r][n], 0, 0, 0);
-          acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[sl][r].y, xv[sl][n].y, acc[r][n], 0, 0, 0);
-          acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[sl][r].z, xv[sl][n].z, acc[r][n], 0, 0, 0);
-          acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[sl][r].w, xv[sl][n].w, acc[r][n], 0, 0, 0);
-        }
+      // issue order: the four k-slices outermost, so that consecutive MFMAs write different accumulators
+      // (back-to-back MFMAs on one accumulator wait for each other's result: 60 % of the wave cycles of
+      // this launch were issue stalls with the slices innermost)
+#define TTSX_SLICE(C)                                                                                        \
+  _Pragma("unroll") for (int r = 0; r < R; ++r) _Pragma("unroll") for (int n = 0; n < NT; ++n) acc[r][n] =  \
+      __builtin_amdgcn_mfma_f32_16x16x4f32(wv[sl][r].C, xv[sl][n].C, acc[r][n], 0, 0, 0);
+      TTSX_SLICE(x)
+      TTSX_SLICE(y)
+      TTSX_SLICE(z)
+      TTSX_SLICE(w)
+#undef TTSX_SLICE
       if (i + D < KGW) {
 #pragma unroll
         for (int r = 0; r < R; ++r) wv[sl][r] = W[(size_t)(i + D) * GEMM_WAVES * 64 + r * wrs];
@@ -418,11 +432,13 @@ struct GemmOp {
         for (int n = 0; n < NT; ++n) xv[sl][n] = xp[n * 16];
       }
     }
+    if (KGW == 20) FA_MARK(9);
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
       for (int n = 0; n < NT; ++n) red[wave][r * NT + n][lane] = acc[r][n];
     __syncthreads();
+    if (KGW == 20) FA_MARK(10);
     if (done) return;
 
     // wave w finishes tile w: lane l holds rows 4*(l>>4)+{0..3} of column l&15
@@ -436,6 +452,7 @@ struct GemmOp {
       const float h = epilogue_quad<MODE>(p, (rb + t / NT) * 4 + (lane >> 4), b0 + (t % NT) * 16 + (lane & 15), v, pre[k]);
       if (MODE == MODE_LSTM || MODE == MODE_GRU) s_h[(t / NT) * 4 + (lane >> 4)][(t % NT) * 16 + (lane & 15)] = h;
     }
+    if (KGW == 20) FA_MARK(11);
     if (qshare) {
       __syncthreads();
       const int d = threadIdx.x & (ATT_DIM - 1), c0 = (threadIdx.x >> 7) * QC;
@@ -1055,13 +1072,6 @@ struct GravesOp {
 // waits for every outstanding global load as well - including loads issued early on purpose.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-#ifdef TTSX_FA_TIMING
-// phase timestamps of workgroup 0 (100 MHz wall clock), for tuning builds only
-__device__ long long g_fa_t[8];
-#define FA_MARK(i) do { if (wg == 0 && threadIdx.x == 0) g_fa_t[i] = wall_clock64(); } while (0)
-#else
-#define FA_MARK(i) do { } while (0)
-#endif
 constexpr int FA_TMAX = 512, FA_CF_PITCH = 36, FA_SA_LEN = FA_TMAX + 48;
 constexpr int FA_LDS_FLOATS = 2048 + 4096 + 2 * FA_SA_LEN + GEMM_WAVES * 16 * FA_CF_PITCH + 512 + 128 + 128 + 2 * FA_TMAX;
 template <int NTT, int EDIM>
@@ -2491,7 +2501,7 @@ extern "C" int ttsx_add_speaker_embedding(float* enc, const float* table, const 
 
 #ifdef TTSX_FA_TIMING
 extern "C" int ttsx_debug_fa_timing(long long* out_host) {
-  TTSX_HIP(hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_fa_t), sizeof(long long) * 8));
+  TTSX_HIP(hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_fa_t), sizeof(long long) * 16));
   return TTSX_OK;
 }
 #endif
