@@ -29,6 +29,7 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(_lib.CbhgWeights) == 16 + 8 * 115
     assert ctypes.sizeof(_lib.T1Weights) == 2 * (16 + 8 * 115) + 8 * 39
     assert ctypes.sizeof(_lib.EncoderLstmWeights) == 8 * 8
+    assert ctypes.sizeof(_lib.T2AttentionOptions) == 16 + 16 + 8 + 32   # 4 ints, 2 pointers, int + pad, 4 pointers
     assert ctypes.sizeof(_lib.StftParams) == 16
     assert ctypes.sizeof(_lib.AudioParams) == 28
 
