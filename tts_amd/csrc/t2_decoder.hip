@@ -1146,18 +1146,24 @@ struct FusedAttnOp {
     if (tid < ATT_DIM) s_v[tid] = vw;
     __syncthreads();
     FA_MARK(1);
-    // The encoder rows of the first 128 positions are requested now and wait in registers (one
-    // workgroup per CU: the register file is otherwise idle), so the context costs no memory round
-    // trip at the end.  Not earlier: vector loads return in order and the barrier above would have
-    // waited for these 256 KB as well (measured: 4.3 us instead of 2.1 us to reach it).
+    // The encoder rows of the first positions wait in registers for the context (one workgroup per CU:
+    // the register file is otherwise idle), so it costs no memory round trip at the end.  They are
+    // requested in the shadow of the dense MFMAs below, a few per d-tile: 256 KB through one CU's
+    // address unit is ~2.5 us of issue when requested in one go, and requested before the first barrier
+    // they would have delayed it as well (vector loads return in order: 4.3 us instead of 2.1 us).
     constexpr int LPR = EDIM / 4, RG = CTX_THREADS / LPR;
     const int cl = tid % LPR, rg = tid / LPR;
     const float4* e4 = reinterpret_cast<const float4*>(p.enc + (size_t)b * T * EDIM) + cl;
     constexpr int FA_PRE = NTT == 1 ? 128 / RG : 16;  // (more tiles per wave leave fewer registers free)
     float4 pre[FA_PRE];
     const int t_last = max(len - 1, 0);
+    constexpr int PRE_DT = FA_PRE / 8;  // loads per d-tile
+    const bool has_tile = wave < ((T + 15) >> 4);
+    if (!has_tile) {
+      // a wave without a position tile has nothing to hide them behind
 #pragma unroll
-    for (int i = 0; i < FA_PRE; ++i) pre[i] = e4[(size_t)min(rg + i * RG, t_last) * (EDIM / 4)];  // (masked at use)
+      for (int i = 0; i < FA_PRE; ++i) pre[i] = e4[(size_t)min(rg + i * RG, t_last) * (EDIM / 4)];  // (masked at use)
+    }
     if (tid < ATT_DIM) {
       float acc = 0.f;
 #pragma unroll
@@ -1196,6 +1202,11 @@ struct FusedAttnOp {
       float esum = 0.f;
 #pragma unroll
       for (int dt = 0; dt < 8; ++dt) {
+        if (i == 0) {
+#pragma unroll
+          for (int u = 0; u < PRE_DT; ++u)
+            pre[dt * PRE_DT + u] = e4[(size_t)min(rg + (dt * PRE_DT + u) * RG, t_last) * (EDIM / 4)];
+        }
         const float* wa = s_wld + dt * 8 * 64 + lane;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[0 * 64], bq0.x, acc, 0, 0, 0);
