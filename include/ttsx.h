@@ -327,7 +327,7 @@ int ttsx_t1_encoder_run(ttsx_t1* m, const float* emb, const int32_t* lengths, in
  * lengths [B] int32 or NULL as above: attention runs over the first lengths[b] positions and the
  * stop rule uses that length; align columns beyond it are zero.  Rows of mel / align / stop past
  * n_steps[b] are not written.  T <= 512.  Synchronises `stream`.
- * Runs as eight launches per step over the whole chip (a hipGraph per 32 steps); the environment
+ * Runs as seven launches per step over the whole chip (a hipGraph per 32 steps); the environment
  * variable TTSX_T1_PERSISTENT=1 selects the one-workgroup-per-utterance kernel instead. */
 int ttsx_t1_decoder_run(ttsx_t1* m, const float* enc, const int32_t* lengths, int B, int T, int max_decoder_steps,
                         float* mel, float* align, float* stop, int32_t* n_steps, int* steps_run_host, void* stream);

@@ -213,6 +213,7 @@ struct GemmP {
   // GRU (Tacotron v1; rows of a hidden unit = r, z, n_input, n_hidden over K = [x; h]): h ping-pong in
   // `out` like the LSTM; with `resid` the launch also writes sum_out = h_new + resid (residual GRU stack)
   const float* resid;
+  const float* resid2;  // optional second residual term
   float* sum_out;
   // MEL (Tacotron v1 proj_to_mel): sigmoid frames to out[0], to the run's mel rows and to the tail of the
   // next memory queue (quads mem_keep .. mem_keep + o_quads - 1 of mem_new)
@@ -248,6 +249,7 @@ __device__ __forceinline__ Pre prefetch_quad(const GemmP& p, int quad, int b) {
     const float* h_in = p.parity ? p.out[1] : p.out[0];  // the state before this step
     r.c = h_in[qidx(quad, b, p.Bpad)];
     if (p.resid) r.gates.x = p.resid[qidx(quad, b, p.Bpad)];
+    if (p.resid2) r.gates.y = p.resid2[qidx(quad, b, p.Bpad)];
   }
   return r;
 }
@@ -286,7 +288,7 @@ __device__ __forceinline__ float epilogue_quad(const GemmP& p, int quad, int b, 
     const float h_new = (1.f - zg) * ng + zg * pre.c;
     float* h_out = p.parity ? p.out[0] : p.out[1];
     h_out[idx] = h_new;
-    if (p.sum_out) p.sum_out[idx] = h_new + pre.gates.x;
+    if (p.sum_out) p.sum_out[idx] = (h_new + pre.gates.x) + pre.gates.y;
     return h_new;
   } else if (MODE == MODE_MEL) {
     RunCtx* cx = p.ctx;
@@ -2522,8 +2524,12 @@ extern "C" int ttsx_debug_fa_timing(long long* out_host) {
 // LocationSensitiveAttention (:71-88), Prenet (:250-253) and StopNet (:663-667) as a chain of eight
 // launches per step on the row-block engine:
 //   prenet-1 (+ the stop rule of the previous step as a side op) | prenet-2 | attention GRU (+ query
-//   shares) | fused attention | project_to_decoder_in | GRU 1 (+ residual) | GRU 2 (+ residual) |
+//   shares) | fused attention | GRU 1 (+ project_to_decoder_in as a side op) | GRU 2 (+ residuals) |
 //   proj_to_mel + sigmoid (+ the memory-queue shift as a side op)
+// project_to_decoder_in is linear, so GRU 1 takes its input weights composed with it and runs straight
+// on [h_att; context; h] while d0 = Wd [h_att; context] + bd is produced next to it in the same launch;
+// the residual d1 = h1 + d0 is never formed: GRU 2 multiplies its input weights with h1 and with d0 as two
+// segments and adds both to its own output (d2 = h2 + h1 + d0).
 // A GRU cell fits the engine's four-rows-per-hidden-unit layout as rows (r, z, n_input, n_hidden) over
 // K = [x; h], the two n rows zero-padded over the half they do not see.  All biases of the energy
 // (query, annotation, location-linear) are constants of the step and are added once (P carries the
@@ -2555,6 +2561,32 @@ __global__ void gru_expand_kernel(float* __restrict__ w4, float* __restrict__ b4
     else if (g == 3) v = w_hh[(size_t)(2 * H + u) * kh + (k - kx)];
   }
   w4[i] = v;
+}
+
+// GRU input weights composed with a preceding bias-carrying linear layer x = Wd y + bd (no activation
+// between the two): w_c[row][k] = sum_j w_ih[row][j] wd[j][k], b_c[row] = b_ih[row] + sum_j w_ih[row][j] bd[j]
+// (fp64 accumulation, once at create).  One block per row.
+__global__ void compose_gru_input_kernel(float* __restrict__ w_c, float* __restrict__ b_c, const float* __restrict__ w_ih,
+                                         const float* __restrict__ b_ih, const float* __restrict__ wd,
+                                         const float* __restrict__ bd, int kin, int ky) {
+  const int row = blockIdx.x;
+  for (int k = threadIdx.x; k < ky; k += blockDim.x) {
+    double acc = 0.0;
+    for (int j = 0; j < kin; ++j) acc += (double)w_ih[(size_t)row * kin + j] * (double)wd[(size_t)j * ky + k];
+    w_c[(size_t)row * ky + k] = (float)acc;
+  }
+  if (threadIdx.x == 0) {
+    double acc = b_ih[row];
+    for (int j = 0; j < kin; ++j) acc += (double)w_ih[(size_t)row * kin + j] * (double)bd[j];
+    b_c[row] = (float)acc;
+  }
+}
+// [w | w]: the same input weights over two activation segments whose sum is the layer's input
+__global__ void dup_cols_kernel(float* __restrict__ dst, const float* __restrict__ src, int rows, int k) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)rows * 2 * k) return;
+  const int row = (int)(i / (2 * k)), c = (int)(i % (2 * k));
+  dst[i] = src[(size_t)row * k + (c % k)];
 }
 
 // the part of the memory queue that survives a step: quads [drop, drop + n) of the old queue -> [0, n)
@@ -2678,6 +2710,7 @@ T1StopOp::P t1_stop_params(const t1_steps* s, int idx) {
 
 // One decoder step (index i of the chunk; `parity` = steps completed before it, & 1).
 int t1_enqueue_step(t1_steps* s, int B, int T, int i, int parity, hipStream_t st) {
+  float* const h1_new = parity ? s->h_d1[0] : s->h_d1[1];  // hidden state GRU 1 writes in this step
   const int Bpad = s->Bpad;
   int rc;
   GemmP g{};
@@ -2722,25 +2755,38 @@ int t1_enqueue_step(t1_steps* s, int B, int T, int i, int parity, hipStream_t st
     else dual_kernel<FusedAttnOp<4, T1_ENC>, NoOp><<<B, GEMM_THREADS, smem, st>>>(ap, 0, B);
     TTSX_LAUNCH_CHECK();
   }
-  // decoder input = project_to_decoder_in([h_att; context])
-  g.Wp = s->w_pd, g.bias = s->b_pd, g.nseg = 2, g.KG = (T1_RNN + T1_ENC) / 16, g.kg_stride = g.KG;
-  g.seg[0] = Seg{{s->h_att[0], s->h_att[1]}, 2, T1_RNN / 16};
-  g.seg[1] = Seg{{s->ctx, nullptr}, 0, T1_ENC / 16};
-  g.out[0] = s->d0, g.out[1] = nullptr;
-  if ((rc = t1_launch<MODE_LINEAR, 4, NoOp>(s, B, g, T1_RNN / 16, 0, 0, st))) return rc;
-  // the two residual GRUs
-  g.nseg = 2, g.KG = 2 * T1_RNN / 16, g.kg_stride = g.KG;
-  g.Wp = s->w_g1, g.bias = s->b_g1;
-  g.seg[0] = Seg{{s->d0, nullptr}, 0, T1_RNN / 16};
-  g.seg[1] = Seg{{s->h_d1[0], s->h_d1[1]}, 1, T1_RNN / 16};
-  g.out[0] = s->h_d1[0], g.out[1] = s->h_d1[1], g.resid = s->d0, g.sum_out = s->d1;
-  if ((rc = t1_launch<MODE_GRU, 4, NoOp>(s, B, g, T1_RNN / 4, 0, 0, st))) return rc;
+  // GRU 1 on [h_att; context; h1] with composed input weights   (+ d0 = project_to_decoder_in([h_att; context]))
+  {
+    GemmP gd = g;
+    gd.Wp = s->w_pd, gd.bias = s->b_pd, gd.nseg = 2, gd.KG = (T1_RNN + T1_ENC) / 16, gd.kg_stride = gd.KG;
+    gd.seg[0] = Seg{{s->h_att[0], s->h_att[1]}, 2, T1_RNN / 16};
+    gd.seg[1] = Seg{{s->ctx, nullptr}, 0, T1_ENC / 16};
+    gd.out[0] = s->d0, gd.out[1] = nullptr, gd.relu = 0, gd.rb0 = 0, gd.nrb = T1_RNN / 16;
+    g.Wp = s->w_g1, g.bias = s->b_g1, g.nseg = 3, g.KG = (2 * T1_RNN + T1_ENC) / 16, g.kg_stride = g.KG;
+    g.seg[0] = Seg{{s->h_att[0], s->h_att[1]}, 2, T1_RNN / 16};
+    g.seg[1] = Seg{{s->ctx, nullptr}, 0, T1_ENC / 16};
+    g.seg[2] = Seg{{s->h_d1[0], s->h_d1[1]}, 1, T1_RNN / 16};
+    g.out[0] = s->h_d1[0], g.out[1] = s->h_d1[1], g.rb0 = 0, g.nrb = T1_RNN / 4;
+    const int nrb = T1_RNN / 4, nside = T1_RNN / 16;
+    if (B == 1) {
+      dual_kernel<GemvOp<1, 6, MODE_GRU>, GemvOp<1, 4, MODE_LINEAR>><<<nrb + nside, GEMM_THREADS, 0, st>>>(g, gd, nrb);
+    } else if (B == 2) {
+      dual_kernel<GemvOp<2, 6, MODE_GRU>, GemvOp<2, 4, MODE_LINEAR>><<<nrb + nside, GEMM_THREADS, 0, st>>>(g, gd, nrb);
+    } else {
+      const int nt = Bpad / 16;
+      dual_kernel<GemmOp<1, 1, 6, MODE_GRU>, GemmOp<1, 1, 4, MODE_LINEAR>><<<(nrb + nside) * nt, GEMM_THREADS, 0, st>>>(
+          g, gd, nrb * nt);
+    }
+    TTSX_LAUNCH_CHECK();
+  }
+  // GRU 2 on [h1; d0; h2] (its input weights over both terms of d1 = h1 + d0); d2 = h2 + h1 + d0
   g.Wp = s->w_g2, g.bias = s->b_g2;
-  g.seg[0] = Seg{{s->d1, nullptr}, 0, T1_RNN / 16};
-  g.seg[1] = Seg{{s->h_d2[0], s->h_d2[1]}, 1, T1_RNN / 16};
-  g.out[0] = s->h_d2[0], g.out[1] = s->h_d2[1], g.resid = s->d1, g.sum_out = s->d2;
-  if ((rc = t1_launch<MODE_GRU, 4, NoOp>(s, B, g, T1_RNN / 4, 0, 0, st))) return rc;
-  g.resid = nullptr, g.sum_out = nullptr;
+  g.seg[0] = Seg{{s->h_d1[0], s->h_d1[1]}, 2, T1_RNN / 16};
+  g.seg[1] = Seg{{s->d0, nullptr}, 0, T1_RNN / 16};
+  g.seg[2] = Seg{{s->h_d2[0], s->h_d2[1]}, 1, T1_RNN / 16};
+  g.out[0] = s->h_d2[0], g.out[1] = s->h_d2[1], g.resid = h1_new, g.resid2 = s->d0, g.sum_out = s->d2;
+  if ((rc = t1_launch<MODE_GRU, 6, NoOp>(s, B, g, T1_RNN / 4, 0, 0, st))) return rc;
+  g.resid = nullptr, g.resid2 = nullptr, g.sum_out = nullptr;
   // mel frames   (+ the surviving part of the memory queue)
   g.Wp = s->w_mel, g.bias = s->b_mel, g.nseg = 1, g.KG = T1_RNN / 16, g.kg_stride = g.KG;
   g.seg[0] = Seg{{s->d2, nullptr}, 0, T1_RNN / 16};
@@ -2814,8 +2860,24 @@ int t1_steps_create(const T1StepWeights* w, hipStream_t st, t1_steps** out) {
   rc |= pack_layer(&s->w_pre1, &s->b_pre1, w->pre_w1, T1_PRE0, nullptr, 0, w->pre_b1, nullptr, T1_PRE1, 0, st);
   rc |= t1_pack_gru(&s->w_att, &s->b_att, w->att_w_ih, w->att_w_hh, w->att_b_ih, w->att_b_hh, T1_PRE1 + T1_ENC, st);
   rc |= pack_layer(&s->w_pd, &s->b_pd, w->pd_w, T1_RNN + T1_ENC, nullptr, 0, w->pd_b, nullptr, T1_RNN, 0, st);
-  rc |= t1_pack_gru(&s->w_g1, &s->b_g1, w->rnn_w_ih[0], w->rnn_w_hh[0], w->rnn_b_ih[0], w->rnn_b_hh[0], T1_RNN, st);
-  rc |= t1_pack_gru(&s->w_g2, &s->b_g2, w->rnn_w_ih[1], w->rnn_w_hh[1], w->rnn_b_ih[1], w->rnn_b_hh[1], T1_RNN, st);
+  {
+    // GRU 1: input weights composed with project_to_decoder_in; GRU 2: input weights over [h1 | d0]
+    float *w_c = nullptr, *b_c = nullptr, *w_dup = nullptr;
+    const int K = T1_RNN + T1_ENC;
+    if (dev_alloc(&w_c, (size_t)3 * T1_RNN * K) || dev_alloc(&b_c, 3 * T1_RNN) ||
+        dev_alloc(&w_dup, (size_t)3 * T1_RNN * 2 * T1_RNN))
+      return TTSX_ERR_HIP;
+    compose_gru_input_kernel<<<3 * T1_RNN, 256, 0, st>>>(w_c, b_c, w->rnn_w_ih[0], w->rnn_b_ih[0], w->pd_w, w->pd_b,
+                                                         T1_RNN, K);
+    TTSX_LAUNCH_CHECK();
+    const size_t nd = (size_t)3 * T1_RNN * 2 * T1_RNN;
+    dup_cols_kernel<<<(unsigned)((nd + 255) / 256), 256, 0, st>>>(w_dup, w->rnn_w_ih[1], 3 * T1_RNN, T1_RNN);
+    TTSX_LAUNCH_CHECK();
+    rc |= t1_pack_gru(&s->w_g1, &s->b_g1, w_c, w->rnn_w_hh[0], b_c, w->rnn_b_hh[0], K, st);
+    rc |= t1_pack_gru(&s->w_g2, &s->b_g2, w_dup, w->rnn_w_hh[1], w->rnn_b_ih[1], w->rnn_b_hh[1], 2 * T1_RNN, st);
+    TTSX_HIP(hipStreamSynchronize(st));
+    (void)hipFree(w_c), (void)hipFree(b_c), (void)hipFree(w_dup);
+  }
   rc |= pack_layer(&s->w_mel, &s->b_mel, w->mel_w, T1_RNN, nullptr, 0, w->mel_b, nullptr, w->odim, 0, st);
   if (rc) return TTSX_ERR_HIP;
   if (dev_alloc(&s->wlc_p, 2 * 16 * 64) || dev_alloc(&s->wld_p, 8 * 8 * 64) || dev_alloc(&s->wq_t, (size_t)QUERY_DIM * ATT_DIM) ||
