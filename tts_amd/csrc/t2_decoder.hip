@@ -1729,7 +1729,9 @@ hipError_t set_fused_lds_for() {
 }
 hipError_t set_fused_lds() {
   hipError_t e = set_fused_lds_for<FusedAttnOp<1, ENC_DIM>>();
-  return e != hipSuccess ? e : set_fused_lds_for<FusedAttnOp<2, ENC_DIM>>();
+  if (e != hipSuccess) return e;
+  if ((e = set_fused_lds_for<FusedAttnOp<2, ENC_DIM>>()) != hipSuccess) return e;
+  return set_fused_lds_for<FusedAttnOp<4, ENC_DIM>>();
 }
 
 // Early columns of the attention LSTM, [ctx(t-1); h_a(t-1)] -> g_a, for the step with chunk index i.
@@ -1825,7 +1827,8 @@ int enqueue_step(ttsx_t2_decoder* d, int i, bool first, bool more, hipStream_t s
     pc.g.rb0 = 0, pc.g.nrb = pd.total_rb;
     const size_t smem = sizeof(float) * FA_LDS_FLOATS;
     if (T <= 128) rc = launch_with_piece<FusedAttnOp<1, ENC_DIM>, PK2>(d, ap, B, smem, &pc, st);
-    else rc = launch_with_piece<FusedAttnOp<2, ENC_DIM>, PK2>(d, ap, B, smem, &pc, st);
+    else if (T <= 256) rc = launch_with_piece<FusedAttnOp<2, ENC_DIM>, PK2>(d, ap, B, smem, &pc, st);
+    else rc = launch_with_piece<FusedAttnOp<4, ENC_DIM>, PK2>(d, ap, B, smem, &pc, st);
     if (rc) return rc;
   } else {
   // query projection   (+ first third of the decoder partial)
@@ -2126,7 +2129,9 @@ extern "C" int ttsx_t2_decoder_begin(ttsx_t2_decoder* d, const float* enc, const
     // B=128 79.4 / 87.0, B=64 T=256 58.3 / 62.9; at B=1 it is a tie (32.8 / 33.0): the kernel moves
     // ~260 KB through ONE CU's vector memory pipe and that costs what the two saved launches did.
     const char* f = getenv("TTSX_FUSED_ATTN");
-    d->fused = T <= 256 && !d->variant && !graves && !(f && f[0] == '0') &&
+    // One workgroup walks all positions of its utterance: past 256 positions that only pays when the batch
+    // fills a good part of the chip (measured: B=64 T=512 79 -> 72 us/step, B=16 T=512 49 -> 59).
+    d->fused = (T <= 256 || (T <= FA_TMAX && B >= 48)) && !d->variant && !graves && !(f && f[0] == '0') &&
                (B > GEMV_MAX_B || (f && f[0] == '1'));
   }
   d->parity0 = 0;
