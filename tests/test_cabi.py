@@ -50,3 +50,63 @@ def test_no_cpu_fallback_in_product_path():
         m.load_state_dict(synthetic.t2_state_dict(0))
         with pytest.raises(_lib.TtsxError):
             m.inference(torch.zeros(1, 5, dtype=torch.long))
+
+
+def test_entry_points_reject_bad_arguments_before_any_device_call():
+    """Null handles / pointers and out-of-range sizes come back as TTSX_ERR_ARG with a message naming the entry
+    point; the check precedes every HIP call, so it runs (and must not crash) on a machine without a GPU."""
+    from ctypes import byref, c_int, c_long, c_float, c_void_p
+    from tts_amd import _lib
+    lib = _lib.load()
+    one = c_void_p(256)   # a non-null pointer that is never dereferenced on these paths
+    out = c_void_p()
+    n = c_int()
+    sp = _lib.StftParams(2048, 275, 1100, 0)
+    calls = {
+        "ttsx_t2_decoder_create": lambda: lib.ttsx_t2_decoder_create(None, 7, 0, None, byref(out)),
+        "ttsx_t2_decoder_set_attention": lambda: lib.ttsx_t2_decoder_set_attention(None, None, None),
+        "ttsx_t2_decoder_set_initial": lambda: lib.ttsx_t2_decoder_set_initial(None, 0, None, 1, None),
+        "ttsx_t2_decoder_run": lambda: lib.ttsx_t2_decoder_run(None, one, None, 1, 8, 1, 10, 0.5, 0, one, one, one,
+                                                               one, byref(n), None),
+        "ttsx_t2_decoder_begin": lambda: lib.ttsx_t2_decoder_begin(None, one, None, 1, 8, None),
+        "ttsx_t2_decoder_load_state": lambda: lib.ttsx_t2_decoder_load_state(None, *([None] * 7), None),
+        "ttsx_t2_decoder_step": lambda: lib.ttsx_t2_decoder_step(None, one, 1, one, one, one, None),
+        "ttsx_t2_decoder_read_state": lambda: lib.ttsx_t2_decoder_read_state(None, *([None] * 7), None),
+        "ttsx_postnet_create": lambda: lib.ttsx_postnet_create(None, None, byref(out)),
+        "ttsx_postnet_run": lambda: lib.ttsx_postnet_run(None, one, None, 1, 8, one, None),
+        "ttsx_encoder_convs_create": lambda: lib.ttsx_encoder_convs_create(None, None, byref(out)),
+        "ttsx_encoder_convs_run": lambda: lib.ttsx_encoder_convs_run(None, one, None, 1, 8, one, None),
+        "ttsx_encoder_lstm_create": lambda: lib.ttsx_encoder_lstm_create(None, None, byref(out)),
+        "ttsx_encoder_lstm_run": lambda: lib.ttsx_encoder_lstm_run(None, one, None, 1, 8, one, None),
+        "ttsx_encoder_lstm_run_stateful": lambda: lib.ttsx_encoder_lstm_run_stateful(None, one, None, 1, 8, one, None,
+                                                                                     None, None),
+        "ttsx_add_speaker_embedding": lambda: lib.ttsx_add_speaker_embedding(one, one, None, 4, 1, 8, None),
+        "ttsx_t1_create": lambda: lib.ttsx_t1_create(None, 5, 5, 1025, None, byref(out)),
+        "ttsx_t1_encoder_run": lambda: lib.ttsx_t1_encoder_run(None, one, None, 1, 8, one, None),
+        "ttsx_t1_decoder_run": lambda: lib.ttsx_t1_decoder_run(None, one, None, 1, 8, 10, one, one, one, one, byref(n),
+                                                               None),
+        "ttsx_t1_postnet_run": lambda: lib.ttsx_t1_postnet_run(None, one, None, 1, 8, one, None),
+        "ttsx_spec_to_mag": lambda: lib.ttsx_spec_to_mag(None, None, 1, 8, 80, 1025, None, one, None),
+        "ttsx_griffin_lim": lambda: lib.ttsx_griffin_lim(None, one, None, 1, 8, byref(sp), 60, 1.0, one, None),
+        "ttsx_stft": lambda: lib.ttsx_stft(None, 1, 8, byref(sp), one, one, None),
+        "ttsx_istft": lambda: lib.ttsx_istft(None, one, 1, 8, byref(sp), one, None),
+        "ttsx_request_tail": lambda: lib.ttsx_request_tail(None, None, 1, 100, 1024, 256, -40.0, 0, 0, one, one, one,
+                                                           c_long(100), None, None, None),
+    }
+    skipped = {"ttsx_last_error_string", "ttsx_version"}
+    destroys = {k for k in _lib.PROTOTYPES if k.endswith("_destroy")}
+    assert set(calls) | skipped | destroys == set(_lib.PROTOTYPES)
+    for name, call in calls.items():
+        assert call() == _lib.ERR_ARG, name
+        msg = lib.ttsx_last_error_string().decode()
+        assert msg, name
+    for name in destroys:       # destroying nothing is not an error (free(NULL) semantics)
+        assert getattr(lib, name)(None) == _lib.OK, name
+    # shapes and ranges
+    bad_sp = _lib.StftParams(1024, 275, 1100, 0)
+    assert lib.ttsx_stft(one, 1, 8, byref(bad_sp), one, one, None) == _lib.ERR_ARG
+    assert "n_fft" in lib.ttsx_last_error_string().decode()
+    assert lib.ttsx_stft(one, 1, 1, byref(sp), one, one, None) == _lib.ERR_ARG      # a single frame
+    assert lib.ttsx_griffin_lim(one, one, None, 1, 8, byref(sp), -1, 1.0, one, None) == _lib.ERR_ARG
+    assert lib.ttsx_postnet_run(one, one, None, 0, 8, one, None) == _lib.ERR_ARG    # empty batch
+    assert lib.ttsx_encoder_convs_run(one, one, None, 1, 0, one, None) == _lib.ERR_ARG   # empty text
