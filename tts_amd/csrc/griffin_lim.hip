@@ -199,6 +199,10 @@ __device__ __forceinline__ void frame_body(const FrameP& p, int b, int i, float2
     // their phase instead of staying live across the whole loop body
     int lane_a = lane, lane_b = lane, lane_s = lane;
     asm volatile("" : "+v"(lane_a), "+v"(lane_b), "+v"(lane_s));
+    // (ranges restated for the compiler: with them every index is provably a small non-negative number and the
+    // global accesses take the scalar-base + 32-bit lane offset form instead of 64-bit per-lane address arithmetic)
+    __builtin_assume((unsigned)lane_a < 64u && (unsigned)lane_b < 64u && (unsigned)lane_s < 64u);
+    __builtin_assume((unsigned)z < 8u);
 
     // target magnitudes of this lane's bin pairs, requested now so that they land during the analysis FFT
     float mk[8], mm[8], m512 = 0.f;
@@ -240,6 +244,15 @@ __device__ __forceinline__ void frame_body(const FrameP& p, int b, int i, float2
 
     // ---- per-bin work on pairs (k, 1024-k): k = lane + 64 c (c < 8), and bin 512 on lane 0
     const float* mg = p.mag + frow * NBIN;
+    // operands of the eight pairs first (LDS reads cannot be moved across the LDS writes of an earlier pair by
+    // the compiler, so read-compute-write per pair would expose one LDS latency per pair)
+    float2 Zk8[8], Zm8[8], W8[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int k = lane_b + 64 * c;
+      if (KIND == K_GL_ITER || KIND == K_STFT) Zk8[c] = s[pidx(k)], Zm8[c] = s[pidx((MC - k) & (MC - 1))];
+      W8[c] = s_tw2[k + z];
+    }
 #pragma unroll
     for (int c = 0; c < 9; ++c) {
       int k;
@@ -247,13 +260,14 @@ __device__ __forceinline__ void frame_body(const FrameP& p, int b, int i, float2
       else if (lane_b == 0) k = 512;
       else break;
       const int mkk = MC - k;  // partner bin (1024 for k = 0)
+      const float2 W = c < 8 ? W8[c < 8 ? c : 0] : s_tw2[512 + z];
       float2 Xk, Xm;
       if (KIND == K_GL_ITER || KIND == K_STFT) {
-        const float2 Zk = s[pidx(k)], Zm = s[pidx(mkk & (MC - 1))];
+        const float2 Zk = c < 8 ? Zk8[c < 8 ? c : 0] : s[pidx(512)], Zm = c < 8 ? Zm8[c < 8 ? c : 0] : s[pidx(512)];
         const float2 E = make_float2(0.5f * (Zk.x + Zm.x), 0.5f * (Zk.y - Zm.y));
         const float2 D = make_float2(0.5f * (Zk.x - Zm.x), 0.5f * (Zk.y + Zm.y));  // (Zk - conj(Zm))/2
         const float2 O = make_float2(D.y, -D.x);                                  // -i * D
-        const float2 WO = cmul(s_tw2[k + z], O);
+        const float2 WO = cmul(W, O);
         Xk = cadd(E, WO);
         Xm = cconj(csub(E, WO));
       }
@@ -287,9 +301,12 @@ __device__ __forceinline__ void frame_body(const FrameP& p, int b, int i, float2
       // synthesis pre-pass: Z[k] = E + iO, Z[1024-k] = conj(E) + i conj(O)
       const float2 E = make_float2(0.5f * (Xk.x + Xm.x), 0.5f * (Xk.y - Xm.y));
       const float2 D = make_float2(0.5f * (Xk.x - Xm.x), 0.5f * (Xk.y + Xm.y));
-      const float2 O = cmul(D, cconj(s_tw2[k + z]));
-      s[pidx(k)] = make_float2(E.x - O.y, E.y + O.x);
-      if (k != 0) s[pidx(mkk)] = make_float2(E.x + O.y, -E.y + O.x);
+      const float2 O = cmul(D, cconj(W));
+      const float2 zk = make_float2(E.x - O.y, E.y + O.x), zm = make_float2(E.x + O.y, -E.y + O.x);
+      s[pidx(k)] = zk;
+      // (k = 0 has no partner slot: it stores its own value a second time, which keeps the store unconditional
+      // and the eight pairs in one basic block)
+      s[pidx(k ? mkk : 0)] = k ? zm : zk;
     }
     if (KIND == K_STFT) return;
 
@@ -303,6 +320,14 @@ __device__ __forceinline__ void frame_body(const FrameP& p, int b, int i, float2
       // (all lanes have read their last pass from `s` before the first of these stores issues)
       float* dst = TO_LDS ? reinterpret_cast<float*>(s) : p.yw_out + frow * WP;
       const float scale = 1.0f / MC;
+      // the window values of all sixteen sample pairs first (always inside the table), as one burst: a load
+      // inside the range check below would cost one cache round trip per pair
+      float2 wn[16];
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) wn[4 * c + r] = s_win2[lane_s + 64 * c + 256 * r + z];
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int c = 0; c < 4; ++c)
 #pragma unroll
@@ -314,7 +339,7 @@ __device__ __forceinline__ void frame_body(const FrameP& p, int b, int i, float2
 #else
           if (n >= 0 && n < WP) {
 #endif
-            const float2 w = s_win2[m + z];
+            const float2 w = wn[4 * c + r];
             *reinterpret_cast<float2*>(dst + n) = make_float2(v[4 * c + r].x * scale * w.x, v[4 * c + r].y * scale * w.y);
           }
         }
@@ -364,7 +389,9 @@ __global__ __launch_bounds__(64 * FR_PER_WG, 3) void gl_fused_kernel(FusedP P) {
   extern __shared__ float s_carry[];  // [2][carry_len]
   const FrameP& p = P.f;
   const FrameGeom q = p.q;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  // (the wave index through readfirstlane: the compiler then knows that the frame index and every pointer
+  // derived from it are wave-uniform and keeps them in scalar registers)
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int b = blockIdx.y;
   const int Fb = p.n_frames ? p.n_frames[b] : p.F;
   const int L = q.hop * (Fb - 1), Lmax = q.hop * (p.F - 1);
@@ -384,14 +411,15 @@ __global__ __launch_bounds__(64 * FR_PER_WG, 3) void gl_fused_kernel(FusedP P) {
     float acc = 0.f;
 #pragma unroll
     for (int kk = OLA_MAXK - 1; kk >= 0; --kk) {
+      // unconditional (clamped) loads: all of them leave in one burst; behind a condition each would be a
+      // branch with its own wait, 40 dependent round trips before the first frame
       const int n = kk * q.hop + rho;
-      if (kk < K && n < q.win) {
-        const float w = p.winpad[q.lpad + n];
-        acc += w * w;
-      }
+      const float w = p.winpad[min(q.lpad + n, NFFT - 1)];
+      acc += (kk < K && n < q.win) ? w * w : 0.f;
     }
     wss_full[u] = acc;
   }
+  const float inv_hop = 1.0f / (float)q.hop;
   int cur = 0;
   for (int j = j_first - P.n_halo; j < j_end; ++j) {
     if (j < 0) continue;  // uniform: nothing before the first frame
@@ -404,47 +432,65 @@ __global__ __launch_bounds__(64 * FR_PER_WG, 3) void gl_fused_kernel(FusedP P) {
     float* c_new = s_carry + (cur ^ 1) * P.carry_len;
     const int n_out = FR_PER_WG * q.hop;
     const bool emit = j >= j_first;
+    // U positions per thread at a time: their LDS reads (carry + one sample of each of the four frames, clamped
+    // indices, selected afterwards) are all issued before the first use
+    constexpr int U = 4, NT = 64 * FR_PER_WG;
+    const int n_tot = n_out + P.carry_len;
 #pragma unroll 1
-    for (int u = emit ? 0 : n_out / (64 * FR_PER_WG); u * 64 * FR_PER_WG + tid < n_out + P.carry_len; ++u) {
-      const int t = u * 64 * FR_PER_WG + tid;
-      if (!emit && t < n_out) continue;
-      float acc = t < P.carry_len ? c_old[t] : 0.f;
+    for (int t0 = emit ? 0 : (n_out / NT) * NT; t0 < n_tot; t0 += NT * U) {
+      float a[U][FR_PER_WG + 1];
 #pragma unroll
-      for (int w = 0; w < FR_PER_WG; ++w) {
-        const int n = t - w * q.hop;
-        if (n >= 0 && n < q.win && FR_PER_WG * j + w < Fb) acc += reinterpret_cast<const float*>(s_data[w])[n + shift];
-      }
-      if (t >= n_out) {
-        c_new[t - n_out] = acc;
-        continue;
-      }
-      const int a = FR_PER_WG * j * q.hop + t;
-      const int g = q.lpad + a, m = g - NFFT / 2;
-      float y = 0.f;
-      if (m >= 0 && m < L) {
-        // window sum-square over the frames that exist at this position
-        const int sl = FR_PER_WG * j + t / q.hop;
-        float wss = 0.f;
-        if (u < WSS_U && sl >= K - 1 && sl < Fb) {
-          // (a select chain, not an index: keeps the table in registers)
-          wss = u == 0 ? wss_full[0] : u == 1 ? wss_full[1] : u == 2 ? wss_full[2] : u == 3 ? wss_full[3] : wss_full[4];
-        } else {
-          const int rho = t % q.hop;
+      for (int x = 0; x < U; ++x) {
+        const int t = t0 + NT * x + tid;
+        a[x][0] = c_old[max(min(t, P.carry_len - 1), 0)];
 #pragma unroll
-          for (int kk = OLA_MAXK - 1; kk >= 0; --kk) {
-            const int fi = sl - kk, n = kk * q.hop + rho;
-            if (kk < K && fi >= 0 && fi < Fb && n < q.win) {
-              const float w = p.winpad[q.lpad + n];
-              wss += w * w;
+        for (int w = 0; w < FR_PER_WG; ++w)
+          a[x][1 + w] = reinterpret_cast<const float*>(s_data[w])[max(min(t - w * q.hop, q.win - 1), 0) + shift];
+      }
+#pragma unroll
+      for (int x = 0; x < U; ++x) {
+        const int t = t0 + NT * x + tid;
+        if (t >= n_tot || (!emit && t < n_out)) continue;
+        float acc = t < P.carry_len ? a[x][0] : 0.f;
+#pragma unroll
+        for (int w = 0; w < FR_PER_WG; ++w) {
+          const int n = t - w * q.hop;
+          acc += (n >= 0 && n < q.win && FR_PER_WG * j + w < Fb) ? a[x][1 + w] : 0.f;
+        }
+        if (t >= n_out) {
+          c_new[t - n_out] = acc;
+          continue;
+        }
+        const int a_pos = FR_PER_WG * j * q.hop + t;
+        const int g = q.lpad + a_pos, m = g - NFFT / 2;
+        float y = 0.f;
+        if (m >= 0 && m < L) {
+          // window sum-square over the frames that exist at this position
+          const int th = (int)(((float)t + 0.5f) * inv_hop);  // t / hop (exact: the quotient is below 16)
+          const int sl = FR_PER_WG * j + th;
+          const int u = t0 / NT + x;
+          float wss = 0.f;
+          if (u < WSS_U && sl >= K - 1 && sl < Fb) {
+            // (a select chain, not an index: keeps the table in registers)
+            wss = u == 0 ? wss_full[0] : u == 1 ? wss_full[1] : u == 2 ? wss_full[2] : u == 3 ? wss_full[3] : wss_full[4];
+          } else {
+            const int rho = t - th * q.hop;
+#pragma unroll
+            for (int kk = OLA_MAXK - 1; kk >= 0; --kk) {
+              const int fi = sl - kk, n = kk * q.hop + rho;
+              if (kk < K && fi >= 0 && fi < Fb && n < q.win) {
+                const float w = p.winpad[q.lpad + n];
+                wss += w * w;
+              }
             }
           }
+          y = wss > 1.17549435e-38f ? acc / wss : acc;
         }
-        y = wss > 1.17549435e-38f ? acc / wss : acc;
-      }
-      if (PADDED) {
-        if (g < q.LP) P.out[(size_t)b * q.LP + g] = y;
-      } else {
-        if (m >= 0 && m < Lmax) P.out[(size_t)b * Lmax + m] = y;
+        if (PADDED) {
+          if (g < q.LP) P.out[(size_t)b * q.LP + g] = y;
+        } else {
+          if (m >= 0 && m < Lmax) P.out[(size_t)b * Lmax + m] = y;
+        }
       }
     }
     cur ^= 1;
