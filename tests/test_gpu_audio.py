@@ -138,3 +138,22 @@ def test_griffin_lim_two_frames_and_zero_iterations():
         y = ap._griffin_lim(S, init_phase=ph)
         assert y.shape == y_ref.shape == (ap.hop_length,)
         assert _snr_db(y_ref, y) >= 40.0
+
+
+def test_griffin_lim_is_scale_invariant_over_the_float_range():
+    """Griffin-Lim is positively homogeneous: magnitudes scaled by a power of two give the same waveform scaled
+    by it.  At 2^-70 and 2^+52 the squared bin magnitudes leave the float32 range, so the phase normalisation
+    takes its rescaling branch; silence (all-zero magnitudes) must give exact zeros, not NaN."""
+    from tts_amd import synthetic
+    orc, ap = _aps(False, iters=12)
+    F = 24
+    S = orc.spec_from_mel(_smooth_mel(31, 80, F, 1.5)).astype(np.float32)
+    ph = synthetic.gl_init_phase(32, 1025, F)
+    y = ap._griffin_lim(S, init_phase=ph)
+    for e in (-70, 52):
+        c = np.float32(2.0) ** e
+        ys = ap._griffin_lim(S * c, init_phase=ph)
+        assert np.isfinite(ys).all(), e
+        assert _snr_db(y, ys.astype(np.float64) / float(c)) >= 60.0, e
+    z = ap._griffin_lim(np.zeros_like(S), init_phase=ph)
+    assert np.array_equal(z, np.zeros_like(z))

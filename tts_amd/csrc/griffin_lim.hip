@@ -119,7 +119,11 @@ __device__ __forceinline__ void fft1024_tail(float2 (&v)[16], float2* s, const f
   for (int r = 0; r < 16; ++r) v[r] = s[bl + 68 * r];
   const int k = lane & 15;
 #pragma unroll
+#ifdef EXP_TWBCAST
+  for (int r = 1; r < 16; ++r) v[r] = cmul(v[r], tw1024<SIGN>(s_tw, 4 * r + k + z));
+#else
   for (int r = 1; r < 16; ++r) v[r] = cmul(v[r], tw1024<SIGN>(s_tw, 4 * k * r + z));
+#endif
   dft16<SIGN>(v);
   const int j0 = (lane >> 4) * 256 + k;
   const int bj = j0 + (j0 >> 4);  // pidx(j0 + 16 r) = bj + 17 r
@@ -143,6 +147,11 @@ __device__ __forceinline__ void fft1024_tail(float2 (&v)[16], float2* s, const f
 
 // unit phasor of z with np.angle(0) = 0 semantics
 __device__ __forceinline__ float2 unit_phase(float2 z) {
+  const float s = z.x * z.x + z.y * z.y;
+  if (s > 1e-30f && s < 1e30f) {  // the usual case: |z|^2 neither underflows nor overflows
+    const float n = __builtin_amdgcn_rsqf(s);
+    return make_float2(z.x * n, z.y * n);
+  }
   const float r = fmaxf(fabsf(z.x), fabsf(z.y));
   if (!(r > 0.f)) return make_float2(1.f, 0.f);
   const float ir = __builtin_amdgcn_rcpf(r);   // prescale by the larger component: no overflow / underflow
