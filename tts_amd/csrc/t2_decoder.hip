@@ -2123,16 +2123,16 @@ extern "C" int ttsx_t2_decoder_begin(ttsx_t2_decoder* d, const float* enc, const
     // on the MFMA path, where the pieces cost a full activation pass each); TTSX_SPLIT=0 turns it off
     const char* e = getenv("TTSX_SPLIT");
     d->split = B <= GEMV_MAX_B && !(e && e[0] == '0') && !d->variant && !graves;
-    // One-workgroup-per-utterance attention for batches on the MFMA engine and encoder lengths up to
-    // 256 (TTSX_FUSED_ATTN=0: the three-launch path that longer texts take; =1 forces it at batch
-    // 1-2 as well).  Measured per step, fused / three launches: B=16 37.9 / 40.7 us, B=64 51.3 / 54.5,
-    // B=128 79.4 / 87.0, B=64 T=256 58.3 / 62.9; at B=1 it is a tie (32.8 / 33.0): the kernel moves
-    // ~260 KB through ONE CU's vector memory pipe and that costs what the two saved launches did.
+    // One-workgroup-per-utterance attention (TTSX_FUSED_ATTN=0: always the three-launch path; =1: the fused
+    // kernel wherever its shapes allow).  One workgroup walks all positions of its utterance through ONE CU's
+    // vector memory pipe (~2 KB per position), so it pays up to a length that depends on how much of the chip the
+    // batch fills.  Measured per step, fused / three launches:
+    //   B=1:  T=64 30.6 / 33.0 us, T=128 32.5 / 33.7, T=250 39.9 / 33.5      -> up to 128 positions at batch 1-2
+    //   B=16: T=128 37.9 / 40.7, T=512 59 / 49;  B=64: T=128 51.3 / 54.5, T=256 58.3 / 62.9, T=512 72 / 79;
+    //   B=128: T=128 79.4 / 87.0                                              -> 256, and 512 from batch 48 on
     const char* f = getenv("TTSX_FUSED_ATTN");
-    // One workgroup walks all positions of its utterance: past 256 positions that only pays when the batch
-    // fills a good part of the chip (measured: B=64 T=512 79 -> 72 us/step, B=16 T=512 49 -> 59).
-    d->fused = (T <= 256 || (T <= FA_TMAX && B >= 48)) && !d->variant && !graves && !(f && f[0] == '0') &&
-               (B > GEMV_MAX_B || (f && f[0] == '1'));
+    const int t_max = B >= 48 ? FA_TMAX : (B > GEMV_MAX_B || (f && f[0] == '1')) ? 256 : 128;
+    d->fused = T <= t_max && !d->variant && !graves && !(f && f[0] == '0');
   }
   d->parity0 = 0;
   const size_t cb = d->Bpad;
