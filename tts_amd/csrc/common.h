@@ -31,6 +31,21 @@ void ttsx_set_error(const char* fmt, ...);
 
 #define TTSX_LAUNCH_CHECK() TTSX_HIP(hipGetLastError())
 
+// Runs a callable when the scope ends unless dismissed.  The create functions use it to release a half-built
+// handle and their temporaries on every early return (the checking macros above return from the middle).
+template <class F>
+struct ScopeExit {
+  F f;
+  bool armed;
+  explicit ScopeExit(F fn) : f(fn), armed(true) {}
+  ScopeExit(const ScopeExit&) = delete;
+  ScopeExit& operator=(const ScopeExit&) = delete;
+  ~ScopeExit() {
+    if (armed) f();
+  }
+  void dismiss() { armed = false; }
+};
+
 __host__ __device__ static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 __host__ __device__ static inline int round_up(int a, int b) { return ceil_div(a, b) * b; }
 

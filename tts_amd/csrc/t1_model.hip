@@ -160,21 +160,30 @@ int cbhg_create(Cbhg* c, const ttsx_cbhg_weights* w, hipStream_t st) {
   } else {
     TTSX_ARG(c->p1 == 128, "cbhg: no pre_highway but projection width %d != 128", c->p1);
   }
-  std::vector<float*> tmp;
+  std::vector<float*> tmp;  // concatenated source tensors, needed until the packing kernels have run
+  ScopeExit free_tmp([&] {
+    for (float* p : tmp) (void)hipFree(p);
+  });
   for (int i = 0; i < 4; ++i) {
     float *wcat = nullptr, *bcat = nullptr;
-    if ((rc = stack2(&wcat, w->hw_H_w[i], w->hw_T_w[i], 128 * 128, 128 * 128, st))) return rc;
-    if ((rc = stack2(&bcat, w->hw_H_b[i], w->hw_T_b[i], 128, 128, st))) return rc;
-    tmp.push_back(wcat), tmp.push_back(bcat);
+    rc = stack2(&wcat, w->hw_H_w[i], w->hw_T_w[i], 128 * 128, 128 * 128, st);
+    tmp.push_back(wcat);
+    if (rc) return rc;
+    rc = stack2(&bcat, w->hw_H_b[i], w->hw_T_b[i], 128, 128, st);
+    tmp.push_back(bcat);
+    if (rc) return rc;
     if ((rc = convmfma::layer_create(&c->hw[i], wcat, bcat, nullptr, nullptr, nullptr, nullptr, 256, 128, 1, 0,
                                      convmfma::ACT_NONE, 0.f, st)))
       return rc;
   }
   {
     float *wcat = nullptr, *bcat = nullptr;
-    if ((rc = stack2(&wcat, w->gru_w_ih[0], w->gru_w_ih[1], GRU_G * 128, GRU_G * 128, st))) return rc;
-    if ((rc = stack2(&bcat, w->gru_b_ih[0], w->gru_b_ih[1], GRU_G, GRU_G, st))) return rc;
-    tmp.push_back(wcat), tmp.push_back(bcat);
+    rc = stack2(&wcat, w->gru_w_ih[0], w->gru_w_ih[1], GRU_G * 128, GRU_G * 128, st);
+    tmp.push_back(wcat);
+    if (rc) return rc;
+    rc = stack2(&bcat, w->gru_b_ih[0], w->gru_b_ih[1], GRU_G, GRU_G, st);
+    tmp.push_back(bcat);
+    if (rc) return rc;
     if ((rc = convmfma::layer_create(&c->gru_in, wcat, bcat, nullptr, nullptr, nullptr, nullptr, 768, 128, 1, 0,
                                      convmfma::ACT_NONE, 0.f, st)))
       return rc;
@@ -182,7 +191,6 @@ int cbhg_create(Cbhg* c, const ttsx_cbhg_weights* w, hipStream_t st) {
   if ((rc = stack2(&c->w_hh, w->gru_w_hh[0], w->gru_w_hh[1], GRU_G * GRU_H, GRU_G * GRU_H, st))) return rc;
   if ((rc = stack2(&c->b_hh, w->gru_b_hh[0], w->gru_b_hh[1], GRU_G, GRU_G, st))) return rc;
   TTSX_HIP(hipStreamSynchronize(st));
-  for (float* p : tmp) (void)hipFree(p);
   return TTSX_OK;
 }
 
@@ -547,6 +555,8 @@ extern "C" int ttsx_t1_create(const ttsx_t1_weights* w, int r, int memory_size, 
            memory_size);
   hipStream_t st = static_cast<hipStream_t>(stream);
   ttsx_t1* m = new ttsx_t1();
+  ScopeExit on_fail([&] { (void)ttsx_t1_destroy(m); });
+  m->steps = nullptr;
   m->r = r, m->memory_size = memory_size, m->linear_dim = linear_dim;
   m->ws_a = m->ws_b = m->ws_annot = m->post_out = nullptr;
   m->cap_rows_enc = m->cap_rows_post = m->cap_annot = 0;
@@ -621,6 +631,7 @@ extern "C" int ttsx_t1_create(const ttsx_t1_weights* w, int r, int memory_size, 
     if ((rc = t1_steps_create(&sw, st, &m->steps))) return rc;
   }
   TTSX_HIP(hipStreamSynchronize(st));
+  on_fail.dismiss();
   *out = m;
   return TTSX_OK;
 }

@@ -1947,13 +1947,15 @@ extern "C" int ttsx_t2_decoder_create(const ttsx_t2_decoder_weights* w, int r_in
   hipStream_t st = static_cast<hipStream_t>(stream);
   ttsx_t2_decoder* d = new ttsx_t2_decoder();
   memset(d, 0, sizeof(*d));
+  float *w_ih2 = nullptr, *a2f = nullptr, *b2f = nullptr;  // temporaries of the packing
+  ScopeExit on_fail([&] { (void)ttsx_t2_decoder_destroy(d); });
+  ScopeExit free_tmp([&] { (void)hipFree(w_ih2), (void)hipFree(a2f), (void)hipFree(b2f); });
   d->r_init = r_init, d->norm = attn_norm, d->odim = MEL_DIM * r_init;
   int rc = 0;
   rc |= pack_layer(&d->w_lstm1, &d->b_lstm1, w->attn_rnn_w_ih, PRENET_DIM + ENC_DIM, w->attn_rnn_w_hh, QUERY_DIM,
                    w->attn_rnn_b_ih, w->attn_rnn_b_hh, 4 * QUERY_DIM, QUERY_DIM, st);
   // decoder LSTM columns reordered to [ctx; h_a; h_d] so that the late (context) columns and the
   // early ones are each one contiguous run of k-groups
-  float* w_ih2 = nullptr;
   if (dev_alloc(&w_ih2, (size_t)4 * DEC_DIM * (QUERY_DIM + ENC_DIM))) return TTSX_ERR_HIP;
   swap_cols_kernel<<<4 * DEC_DIM, 256, 0, st>>>(w_ih2, w->dec_rnn_w_ih, QUERY_DIM, ENC_DIM);
   TTSX_LAUNCH_CHECK();
@@ -1964,7 +1966,6 @@ extern "C" int ttsx_t2_decoder_create(const ttsx_t2_decoder_weights* w, int r_in
     rc |= pack_layer(&d->w_query, &d->b_query, w->query_w, QUERY_DIM, nullptr, 0, nullptr, nullptr, ATT_DIM, 0, st);
   if (rc) return TTSX_ERR_HIP;
   // prenet: fold BatchNorm, keep layer 1 in source layout for the composed projection rows
-  float *a2f = nullptr, *b2f = nullptr;
   if (dev_alloc(&d->a1f, PRENET_DIM * MEL_DIM) || dev_alloc(&d->b1f, PRENET_DIM) ||
       dev_alloc(&a2f, PRENET_DIM * PRENET_DIM) || dev_alloc(&b2f, PRENET_DIM))
     return TTSX_ERR_HIP;
@@ -2013,9 +2014,9 @@ extern "C" int ttsx_t2_decoder_create(const ttsx_t2_decoder_weights* w, int r_in
   memset(d->rc_host, 0, sizeof(RunCtx));
   TTSX_HIP(hipStreamCreateWithFlags(&d->cap_stream, hipStreamNonBlocking));
   TTSX_HIP(hipStreamSynchronize(st));
-  (void)hipFree(a2f), (void)hipFree(b2f), (void)hipFree(w_ih2);
   rc = ensure_proj(d, r_init, st);
   if (rc) return rc;
+  on_fail.dismiss();
   *out = d;
   return TTSX_OK;
 }
@@ -2380,6 +2381,7 @@ extern "C" int ttsx_encoder_lstm_create(const ttsx_encoder_lstm_weights* w, void
   hipStream_t st = static_cast<hipStream_t>(stream);
   ttsx_encoder_lstm* e = new ttsx_encoder_lstm();
   memset(e, 0, sizeof(*e));
+  ScopeExit on_fail([&] { (void)ttsx_encoder_lstm_destroy(e); });
   int rc = 0;
   for (int d = 0; d < 2; ++d) {
     TTSX_ARG(w->w_ih[d] && w->w_hh[d] && w->b_ih[d] && w->b_hh[d], "ttsx_encoder_lstm_create: null weight");
@@ -2391,6 +2393,7 @@ extern "C" int ttsx_encoder_lstm_create(const ttsx_encoder_lstm_weights* w, void
   TTSX_HIP(hipMalloc(reinterpret_cast<void**>(&e->rc), sizeof(RunCtx)));
   TTSX_HIP(hipMemsetAsync(e->rc, 0, sizeof(RunCtx), st));
   TTSX_HIP(hipStreamSynchronize(st));
+  on_fail.dismiss();
   *out = e;
   return TTSX_OK;
 }
@@ -2838,13 +2841,13 @@ int t1_pack_gru(float** wp, float** bp, const float* w_ih, const float* w_hh, co
                 int kx, hipStream_t st) {
   const int H = T1_RNN, K = kx + H;
   float *w4 = nullptr, *b4 = nullptr;
+  ScopeExit free_tmp([&] { (void)hipFree(w4), (void)hipFree(b4); });
   if (dev_alloc(&w4, (size_t)4 * H * K) || dev_alloc(&b4, 4 * H)) return TTSX_ERR_HIP;
   const size_t n = (size_t)4 * H * K;
   gru_expand_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(w4, b4, w_ih, w_hh, b_ih, b_hh, H, kx, H);
   TTSX_LAUNCH_CHECK();
   int rc = pack_layer(wp, bp, w4, K, nullptr, 0, b4, nullptr, 4 * H, H, st);
   TTSX_HIP(hipStreamSynchronize(st));
-  (void)hipFree(w4), (void)hipFree(b4);
   return rc;
 }
 
@@ -2856,6 +2859,9 @@ int t1_steps_create(const T1StepWeights* w, hipStream_t st, t1_steps** out) {
            "t1_steps_create: memory %d / output %d floats not supported", w->mem_dim, w->odim);
   t1_steps* s = new t1_steps();
   memset(s, 0, sizeof(*s));
+  float *w_c = nullptr, *b_c = nullptr, *w_dup = nullptr;  // temporaries of the packing
+  ScopeExit on_fail([&] { t1_steps_destroy(s); });
+  ScopeExit free_tmp([&] { (void)hipFree(w_c), (void)hipFree(b_c), (void)hipFree(w_dup); });
   s->mem_dim = w->mem_dim, s->odim = w->odim, s->mem_k = round_up(w->mem_dim, 128);
   s->mem_init = w->mem_init, s->att_init = w->att_init, s->rnn_inits = w->rnn_inits;
   int rc = 0;
@@ -2867,7 +2873,6 @@ int t1_steps_create(const T1StepWeights* w, hipStream_t st, t1_steps** out) {
   rc |= pack_layer(&s->w_pd, &s->b_pd, w->pd_w, T1_RNN + T1_ENC, nullptr, 0, w->pd_b, nullptr, T1_RNN, 0, st);
   {
     // GRU 1: input weights composed with project_to_decoder_in; GRU 2: input weights over [h1 | d0]
-    float *w_c = nullptr, *b_c = nullptr, *w_dup = nullptr;
     const int K = T1_RNN + T1_ENC;
     if (dev_alloc(&w_c, (size_t)3 * T1_RNN * K) || dev_alloc(&b_c, 3 * T1_RNN) ||
         dev_alloc(&w_dup, (size_t)3 * T1_RNN * 2 * T1_RNN))
@@ -2881,7 +2886,6 @@ int t1_steps_create(const T1StepWeights* w, hipStream_t st, t1_steps** out) {
     rc |= t1_pack_gru(&s->w_g1, &s->b_g1, w_c, w->rnn_w_hh[0], b_c, w->rnn_b_hh[0], K, st);
     rc |= t1_pack_gru(&s->w_g2, &s->b_g2, w_dup, w->rnn_w_hh[1], w->rnn_b_ih[1], w->rnn_b_hh[1], 2 * T1_RNN, st);
     TTSX_HIP(hipStreamSynchronize(st));
-    (void)hipFree(w_c), (void)hipFree(b_c), (void)hipFree(w_dup);
   }
   rc |= pack_layer(&s->w_mel, &s->b_mel, w->mel_w, T1_RNN, nullptr, 0, w->mel_b, nullptr, w->odim, 0, st);
   if (rc) return TTSX_ERR_HIP;
@@ -2913,6 +2917,7 @@ int t1_steps_create(const T1StepWeights* w, hipStream_t st, t1_steps** out) {
                                  hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
   }
   TTSX_HIP(hipStreamSynchronize(st));
+  on_fail.dismiss();
   *out = s;
   return TTSX_OK;
 }
