@@ -201,6 +201,10 @@ struct GemmP {
   float* gates;        // PARTIAL: raw sums out (quad layout); LSTM: sums of the partial launch, added in
   int gates_pitch;     // columns per quad row of `gates` (0: Bpad) and first column of this launch in it
   int gates_col0;
+  // K cut into parts (MFMA-engine pieces): a PARTIAL launch covers parts kpart0, kpart0+1, ... (one per block of
+  // workgroups, KGW*8 k-groups each) and writes part k to gates + k * gates_part_stride (float4 units); an LSTM
+  // launch adds up `kparts` such buffers.  0 or 1: a single part.
+  int kparts, kpart0, gates_part_stride;
   // LSTM over a sequence (encoder): h also goes to seq_out[b * seq_pitch + unit]; columns whose
   // utterance does not reach time index t_index (t_index >= len[b]) hold zero state and output
   float* seq_out;
@@ -243,7 +247,14 @@ __device__ __forceinline__ Pre prefetch_quad(const GemmP& p, int quad, int b) {
   if (MODE == MODE_LSTM) {
     r.c = p.c[qidx(quad, b, p.Bpad)];
     const int gp = p.gates_pitch ? p.gates_pitch : p.Bpad;
-    if (p.gates) r.gates = reinterpret_cast<const float4*>(p.gates)[(size_t)quad * gp + p.gates_col0 + b];
+    if (p.gates) {
+      const float4* G = reinterpret_cast<const float4*>(p.gates) + (size_t)quad * gp + p.gates_col0 + b;
+      r.gates = G[0];
+      if (p.kparts > 1) {
+        const float4 g2 = G[p.gates_part_stride];
+        r.gates.x += g2.x, r.gates.y += g2.y, r.gates.z += g2.z, r.gates.w += g2.w;
+      }
+    }
   }
   if (MODE == MODE_GRU) {
     const float* h_in = p.parity ? p.out[1] : p.out[0];  // the state before this step
@@ -257,11 +268,13 @@ __device__ __forceinline__ Pre prefetch_quad(const GemmP& p, int quad, int b) {
 // Finish one quad (4 consecutive output rows) of utterance column b.
 // (LSTM: returns the new hidden state of the pair, otherwise 0)
 template <int MODE>
-__device__ __forceinline__ float epilogue_quad(const GemmP& p, int quad, int b, f32x4 v, const Pre& pre) {
+__device__ __forceinline__ float epilogue_quad(const GemmP& p, int quad, int b, f32x4 v, const Pre& pre,
+                                               int kpart = 0) {
   const int Bpad = p.Bpad;
   if (MODE == MODE_PARTIAL) {
     const int gp = p.gates_pitch ? p.gates_pitch : Bpad;
-    reinterpret_cast<float4*>(p.gates)[(size_t)quad * gp + p.gates_col0 + b] = make_float4(v[0], v[1], v[2], v[3]);
+    reinterpret_cast<float4*>(p.gates)[(size_t)kpart * p.gates_part_stride + (size_t)quad * gp + p.gates_col0 + b] =
+        make_float4(v[0], v[1], v[2], v[3]);
     return 0.f;
   }
   v[0] += pre.bias.x, v[1] += pre.bias.y, v[2] += pre.bias.z, v[3] += pre.bias.w;
@@ -354,10 +367,18 @@ __device__ __forceinline__ const float* seg_ptr(const Seg& sg, int parity) {
 template <int R, int NT, int KGW, int MODE>
 struct GemmOp {
   typedef GemmP P;
-  static __device__ __forceinline__ void run(const GemmP& p, int wg) {
+  static __device__ __forceinline__ void run(const GemmP& p, int wg_in) {
+    int wg = wg_in;
     if (KGW == 20) FA_MARK(8);
     const int done = p.ctx->all_done;
     const int ngrp = p.nrb / R;  // row-block groups of this launch
+    int kpart = 0;
+    if (MODE == MODE_PARTIAL && p.kparts > 1) {
+      // one block of workgroups per part of K
+      const int per = ngrp * (p.Bpad / (NT * 16));
+      kpart = wg / per, wg -= kpart * per, kpart += p.kpart0;
+    }
+    const int kbase = kpart * (KGW * GEMM_WAVES);
     const int rb = p.rb0 + (wg % ngrp) * R, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int b0 = (wg / ngrp) * (NT * 16);
 #ifndef TTSX_DMAX_BIG
@@ -368,7 +389,8 @@ struct GemmOp {
     constexpr int TILES = R * NT, TPW = (TILES + GEMM_WAVES - 1) / GEMM_WAVES;
     __shared__ f32x4 red[GEMM_WAVES][TILES][64];
 
-    const float4* W = reinterpret_cast<const float4*>(p.Wp) + ((size_t)rb * p.kg_stride + p.kg0 + wave) * 64 + lane;
+    const float4* W =
+        reinterpret_cast<const float4*>(p.Wp) + ((size_t)rb * p.kg_stride + p.kg0 + kbase + wave) * 64 + lane;
     const size_t wrs = (size_t)p.kg_stride * 64;  // float4 stride between row blocks
     // activation pointers of the (up to three) segments, positioned at this lane's quad row / column
     const size_t xoff = (size_t)(lane >> 4) * p.Bpad + b0 + (lane & 15);
@@ -377,7 +399,8 @@ struct GemmOp {
     const float4* X2 = p.nseg > 2 ? reinterpret_cast<const float4*>(seg_ptr(p.seg[2], p.parity)) + xoff : X0;
     const int e0 = p.seg[0].kgroups, e1 = e0 + (p.nseg > 1 ? p.seg[1].kgroups : 0);
     const size_t xs = (size_t)4 * p.Bpad;  // float4 stride between k-groups
-    auto xptr = [&](int g) -> const float4* {
+    auto xptr = [&](int gl) -> const float4* {
+      const int g = gl + kbase;
       return g < e0 ? X0 + (size_t)g * xs : (g < e1 ? X1 + (size_t)(g - e0) * xs : X2 + (size_t)(g - e1) * xs);
     };
     float4 wv[D][R], xv[D][NT];
@@ -451,7 +474,8 @@ struct GemmOp {
       f32x4 v = red[0][t][lane];
 #pragma unroll
       for (int w = 1; w < GEMM_WAVES; ++w) v += red[w][t][lane];
-      const float h = epilogue_quad<MODE>(p, (rb + t / NT) * 4 + (lane >> 4), b0 + (t % NT) * 16 + (lane & 15), v, pre[k]);
+      const float h =
+          epilogue_quad<MODE>(p, (rb + t / NT) * 4 + (lane >> 4), b0 + (t % NT) * 16 + (lane & 15), v, pre[k], kpart);
       if (MODE == MODE_LSTM || MODE == MODE_GRU) s_h[(t / NT) * 4 + (lane >> 4)][(t % NT) * 16 + (lane & 15)] = h;
     }
     if (KGW == 20) FA_MARK(11);
@@ -1554,8 +1578,8 @@ int ensure_workspace(ttsx_t2_decoder* d, int B, int T) {
     }
     rc |= dev_alloc(&d->c_a, QUERY_DIM * cb);
     rc |= dev_alloc(&d->c_d, DEC_DIM * cb);
-    rc |= dev_alloc(&d->g_a, 4 * QUERY_DIM * cb);
-    rc |= dev_alloc(&d->g_d, 4 * DEC_DIM * cb);
+    rc |= dev_alloc(&d->g_a, 2 * 4 * QUERY_DIM * cb);  // two K parts
+    rc |= dev_alloc(&d->g_d, 2 * 4 * DEC_DIM * cb);
     rc |= dev_alloc(&d->q, ATT_DIM * cb);
     rc |= dev_alloc(&d->o, (size_t)round_up(proj_rows(d), 16) * cb);
     rc |= dev_alloc(&d->len_ws, cb);
@@ -1615,32 +1639,44 @@ int ensure_proj(ttsx_t2_decoder* d, int r, hipStream_t st) {
 struct Piece {
   GemmP g;
   bool on;
+  int nk = 1;  // MFMA engine: K parts this piece covers (g.kpart0 .. g.kpart0 + nk - 1 of g.kparts)
 };
 
-// The two partial launches of a step, each cut into three pieces by row blocks.
+// The two partial launches of a step, each cut into `parts` pieces by row blocks.
 struct Partial {
   GemmP g;
   int total_rb;
-  Piece piece(int k) const {
-    // cuts at 1/3 and 2/3 of the row blocks
+  Piece piece(int k, int parts = 3) const {
     Piece pc{g, true};
-    const int lo = total_rb * k / 3, hi = total_rb * (k + 1) / 3;
+    const int lo = total_rb * k / parts, hi = total_rb * (k + 1) / parts;
     pc.g.rb0 = lo, pc.g.nrb = hi - lo;
     return pc;
   }
 };
 
-// Launch op A (params pa, na workgroups, extra dynamic LDS `smem`) together with a partial piece
-// (GEMV regime only).  PK = k-groups per wave of the partial piece (12: attention LSTM, 16: decoder LSTM).
+// Launch op A (params pa, na workgroups, extra dynamic LDS `smem`) together with a partial piece.
+// PK = k-groups per wave of the partial piece (12: attention LSTM, 16: decoder LSTM).  On the MFMA engine the
+// pieces are cut along K instead of into narrow tiles (32 x 32 tiles keep the activation re-reads down, and half
+// the K range keeps a piece workgroup short enough to pack into the CUs that op A leaves idle).
 template <class A, int PK>
 int launch_with_piece(const ttsx_t2_decoder* d, const typename A::P& pa, int na, size_t smem, const Piece* pc,
                       hipStream_t st) {
   if (!pc || !pc->on) {
     dual_kernel<A, NoOp><<<na, GEMM_THREADS, smem, st>>>(pa, 0, na);
-  } else {
+  } else if (d->B <= GEMV_MAX_B) {
     const int nb = pc->g.nrb;
     if (d->B == 1) dual_kernel<A, GemvOp<1, PK, MODE_PARTIAL>><<<na + nb, GEMM_THREADS, smem, st>>>(pa, pc->g, na);
     else dual_kernel<A, GemvOp<2, PK, MODE_PARTIAL>><<<na + nb, GEMM_THREADS, smem, st>>>(pa, pc->g, na);
+  } else {
+    // K in two parts of PK/2 k-groups per wave, 32 x 32 tiles (16 x 16 when the batch is one column tile)
+    const int nt = d->Bpad / 16;
+    if (nt % 2 == 0 && pc->g.nrb % 2 == 0) {
+      const int nb = pc->g.nrb / 2 * (nt / 2) * pc->nk;
+      dual_kernel<A, GemmOp<2, 2, PK / 2, MODE_PARTIAL>><<<na + nb, GEMM_THREADS, smem, st>>>(pa, pc->g, na);
+    } else {
+      const int nb = pc->g.nrb * nt * pc->nk;
+      dual_kernel<A, GemmOp<1, 1, PK / 2, MODE_PARTIAL>><<<na + nb, GEMM_THREADS, smem, st>>>(pa, pc->g, na);
+    }
   }
   TTSX_LAUNCH_CHECK();
   return TTSX_OK;
@@ -1677,14 +1713,14 @@ int launch_gemm(const ttsx_t2_decoder* d, GemmP g, int nrb, bool big, const Piec
     return launch_with_piece<GemvOp<2, KGW, MODE>, PK>(d, g, nrb, 0, pc, st);
   }
   const int nt_total = d->Bpad / 16;
-  if (!big) return launch_with_piece<GemmOp<1, 1, KGW, MODE>, PK>(d, g, nrb * nt_total, 0, nullptr, st);
+  if (!big) return launch_with_piece<GemmOp<1, 1, KGW, MODE>, PK>(d, g, nrb * nt_total, 0, pc, st);
   const int shape = gemm_shape(d->Bpad, nrb);
   switch (shape) {
-    case 21: return launch_with_piece<GemmOp<2, 1, KGW, MODE>, PK>(d, g, nrb / 2 * nt_total, 0, nullptr, st);
-    case 22: return launch_with_piece<GemmOp<2, 2, KGW, MODE>, PK>(d, g, nrb / 2 * (nt_total / 2), 0, nullptr, st);
-    case 42: return launch_with_piece<GemmOp<4, 2, KGW, MODE>, PK>(d, g, nrb / 4 * (nt_total / 2), 0, nullptr, st);
-    case 24: return launch_with_piece<GemmOp<2, 4, KGW, MODE>, PK>(d, g, nrb / 2 * (nt_total / 4), 0, nullptr, st);
-    default: return launch_with_piece<GemmOp<1, 1, KGW, MODE>, PK>(d, g, nrb * nt_total, 0, nullptr, st);
+    case 21: return launch_with_piece<GemmOp<2, 1, KGW, MODE>, PK>(d, g, nrb / 2 * nt_total, 0, pc, st);
+    case 22: return launch_with_piece<GemmOp<2, 2, KGW, MODE>, PK>(d, g, nrb / 2 * (nt_total / 2), 0, pc, st);
+    case 42: return launch_with_piece<GemmOp<4, 2, KGW, MODE>, PK>(d, g, nrb / 4 * (nt_total / 2), 0, pc, st);
+    case 24: return launch_with_piece<GemmOp<2, 4, KGW, MODE>, PK>(d, g, nrb / 2 * (nt_total / 4), 0, pc, st);
+    default: return launch_with_piece<GemmOp<1, 1, KGW, MODE>, PK>(d, g, nrb * nt_total, 0, pc, st);
   }
 }
 
@@ -1724,7 +1760,11 @@ hipError_t set_fused_lds_for() {
                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes)) != hipSuccess) return e;
   if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(dual_kernel<A, GemvOp<1, PK2, MODE_PARTIAL>>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes)) != hipSuccess) return e;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(dual_kernel<A, GemvOp<2, PK2, MODE_PARTIAL>>),
+  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(dual_kernel<A, GemvOp<2, PK2, MODE_PARTIAL>>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, bytes)) != hipSuccess) return e;
+  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(dual_kernel<A, GemmOp<1, 1, PK2 / 2, MODE_PARTIAL>>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, bytes)) != hipSuccess) return e;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(dual_kernel<A, GemmOp<2, 2, PK2 / 2, MODE_PARTIAL>>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 hipError_t set_fused_lds() {
@@ -1740,6 +1780,7 @@ Partial partial_attn(const ttsx_t2_decoder* d, int i) {
   g.Bpad = d->Bpad, g.ctx = d->rc, g.step_in_chunk = i, g.parity = (d->parity0 + i) & 1;
   g.Wp = d->w_lstm1, g.nseg = 2, g.KG = (ENC_DIM + QUERY_DIM) / 16, g.kg0 = PRENET_DIM / 16, g.kg_stride = KG1;
   g.gates = d->g_a;
+  g.kparts = d->B > GEMV_MAX_B ? 2 : 1, g.gates_part_stride = QUERY_DIM * d->Bpad;
   g.seg[0] = Seg{{d->ctx, nullptr}, 0, ENC_DIM / 16};
   g.seg[1] = Seg{{d->h_a[0], d->h_a[1]}, 1, QUERY_DIM / 16};
   return Partial{g, QUERY_DIM / 4};
@@ -1750,6 +1791,7 @@ Partial partial_dec(const ttsx_t2_decoder* d, int i) {
   g.Bpad = d->Bpad, g.ctx = d->rc, g.step_in_chunk = i, g.parity = (d->parity0 + i) & 1;
   g.Wp = d->w_lstm2, g.nseg = 2, g.KG = (QUERY_DIM + DEC_DIM) / 16, g.kg0 = ENC_DIM / 16, g.kg_stride = KG2;
   g.gates = d->g_d;
+  g.kparts = d->B > GEMV_MAX_B ? 2 : 1, g.gates_part_stride = DEC_DIM * d->Bpad;
   g.seg[0] = Seg{{d->h_a[0], d->h_a[1]}, 2, QUERY_DIM / 16};
   g.seg[1] = Seg{{d->h_d[0], d->h_d[1]}, 1, DEC_DIM / 16};
   return Partial{g, DEC_DIM / 4};
@@ -1772,14 +1814,23 @@ int enqueue_step(ttsx_t2_decoder* d, int i, bool first, bool more, hipStream_t s
   if (split && first) {
     // nothing to hide behind yet: the whole partial as a launch of its own
     pc = Piece{pa.g, true};
-    pc.g.rb0 = 0, pc.g.nrb = pa.total_rb;
+    pc.g.rb0 = 0, pc.g.nrb = pa.total_rb, pc.nk = pa.g.kparts;
     if ((rc = launch_with_piece<NoOp, PK1>(d, 0, 0, 0, &pc, st))) return rc;
   }
+  const bool mfma = B > GEMV_MAX_B;
+  // all rows, one K part (MFMA engine)
+  auto k_piece = [](const Partial& pt, int kpart) {
+    Piece q{pt.g, true};
+    q.g.rb0 = 0, q.g.nrb = pt.total_rb, q.g.kpart0 = kpart, q.nk = 1;
+    return q;
+  };
   // prenet layer 2: x2 = relu(A2f x1 + b2f)   (+ last third of this step's attention partial)
   g.Wp = d->w_pre2, g.bias = d->b_pre2, g.nseg = 1, g.KG = PRENET_DIM / 16, g.kg0 = 0, g.kg_stride = g.KG;
   g.seg[0] = Seg{{d->x1, nullptr}, 0, PRENET_DIM / 16};
   g.out[0] = d->x2, g.relu = 1;
-  pc = pa.piece(2);
+  // (pieces of the attention partial: thirds of the rows behind decoder LSTM / projection / prenet at batch 1-2;
+  // on the MFMA engine the two halves of K behind projection / prenet)
+  pc = mfma ? k_piece(pa, 1) : pa.piece(2);
   pc.on = split && !first;
   if ((rc = launch_gemm<MODE_LINEAR, 2, PK1>(d, g, PRENET_DIM / 16, false, &pc, st))) return rc;
   // attention LSTM: [x2; ctx; h_a] (split: late columns [x2] + the partial sums) + cell update
@@ -1791,7 +1842,9 @@ int enqueue_step(ttsx_t2_decoder* d, int i, bool first, bool more, hipStream_t s
   if (d->fused) g.wq_t = d->wq_t, g.qpart = d->qpart;  // the launch also leaves the shares of the query
   if (split) {
     g.nseg = 1, g.KG = PRENET_DIM / 16, g.gates = d->g_a;
+    g.kparts = pa.g.kparts, g.gates_part_stride = pa.g.gates_part_stride;
     rc = launch_gemm<MODE_LSTM, 2, PK1>(d, g, QUERY_DIM / 4, true, nullptr, st);
+    g.kparts = 0;
   } else {
     g.nseg = 3, g.KG = KG1, g.gates = nullptr;
     rc = launch_gemm<MODE_LSTM, KG1 / GEMM_WAVES, PK1>(d, g, QUERY_DIM / 4, true, nullptr, st);
@@ -1824,7 +1877,7 @@ int enqueue_step(ttsx_t2_decoder* d, int i, bool first, bool more, hipStream_t s
     // query sum + energies + normalisation + context in one launch   (+ the whole decoder partial)
     ap.qpart = d->qpart, ap.n_qgroups = d->qpart_groups, ap.wlc_p = d->wlc_p, ap.wld_p = d->wld_p;
     pc = Piece{pd.g, split};
-    pc.g.rb0 = 0, pc.g.nrb = pd.total_rb;
+    pc.g.rb0 = 0, pc.g.nrb = pd.total_rb, pc.nk = pd.g.kparts;
     const size_t smem = sizeof(float) * FA_LDS_FLOATS;
     if (T <= 128) rc = launch_with_piece<FusedAttnOp<1, ENC_DIM>, PK2>(d, ap, B, smem, &pc, st);
     else if (T <= 256) rc = launch_with_piece<FusedAttnOp<2, ENC_DIM>, PK2>(d, ap, B, smem, &pc, st);
@@ -1872,10 +1925,12 @@ int enqueue_step(ttsx_t2_decoder* d, int i, bool first, bool more, hipStream_t s
   g.seg[2] = Seg{{d->h_d[0], d->h_d[1]}, 1, DEC_DIM / 16};
   g.out[0] = d->h_d[0], g.out[1] = d->h_d[1], g.c = d->c_d;
   pc = pa_next.piece(0);
-  pc.on = split && more;
+  pc.on = split && more && !mfma;
   if (split) {
     g.nseg = 1, g.KG = ENC_DIM / 16, g.gates = d->g_d;
+    g.kparts = pd.g.kparts, g.gates_part_stride = pd.g.gates_part_stride;
     rc = launch_gemm<MODE_LSTM, 4, PK1>(d, g, DEC_DIM / 4, true, &pc, st);
+    g.kparts = 0;
   } else {
     g.nseg = 3, g.KG = KG2, g.gates = nullptr;
     rc = launch_gemm<MODE_LSTM, KG2 / GEMM_WAVES, PK1>(d, g, DEC_DIM / 4, true, nullptr, st);
@@ -1887,7 +1942,7 @@ int enqueue_step(ttsx_t2_decoder* d, int i, bool first, bool more, hipStream_t s
   g.seg[0] = Seg{{d->h_d[0], d->h_d[1]}, 2, DEC_DIM / 16};
   g.seg[1] = Seg{{d->ctx, nullptr}, 0, ENC_DIM / 16};
   g.out[0] = d->o, g.out[1] = nullptr, g.c = nullptr, g.x1 = d->x1, g.o_quads = d->odim / 4;
-  pc = pa_next.piece(1);
+  pc = mfma ? k_piece(pa_next, 0) : pa_next.piece(1);
   pc.on = split && more;
   return launch_gemm<MODE_PROJ, 12, PK1>(d, g, ceil_div(proj_rows(d), 16), false, &pc, st);
 }
@@ -2120,10 +2175,9 @@ extern "C" int ttsx_t2_decoder_begin(ttsx_t2_decoder* d, const float* enc, const
            "ttsx_t2_decoder_begin: encoder length %d exceeds the LDS budget of the attention variants", T);
   d->B = B, d->T = T;
   {
-    // early/late LSTM split: pays where the launches are latency-bound (GEMV regime; measured slower
-    // on the MFMA path, where the pieces cost a full activation pass each); TTSX_SPLIT=0 turns it off
+    // early/late LSTM split: always in the GEMV regime, where every launch is latency-bound (rule for the MFMA
+    // engine below); TTSX_SPLIT=0 turns it off
     const char* e = getenv("TTSX_SPLIT");
-    d->split = B <= GEMV_MAX_B && !(e && e[0] == '0') && !d->variant && !graves;
     // One-workgroup-per-utterance attention (TTSX_FUSED_ATTN=0: always the three-launch path; =1: the fused
     // kernel wherever its shapes allow).  One workgroup walks all positions of its utterance through ONE CU's
     // vector memory pipe (~2 KB per position), so it pays up to a length that depends on how much of the chip the
@@ -2134,6 +2188,13 @@ extern "C" int ttsx_t2_decoder_begin(ttsx_t2_decoder* d, const float* enc, const
     const char* f = getenv("TTSX_FUSED_ATTN");
     const int t_max = B >= 48 ? FA_TMAX : (B > GEMV_MAX_B || (f && f[0] == '1')) ? 256 : 128;
     d->fused = T <= t_max && !d->variant && !graves && !(f && f[0] == '0');
+    // On the MFMA engine the split needs the fused attention launch (one CU per utterance busy for ~11 us: the
+    // shadow the early decoder-LSTM columns run in; the three-launch attention fills the chip itself), and it
+    // pays while the pieces fit into that shadow.  Measured per step, split / whole LSTM launches (T=128 unless
+    // noted): B=4 34.1 / 37.2 us, B=16 33.7 / 37.4, B=32 38.2 / 41.0, B=32 T=256 45.2 / 48.8, B=64 50.3 / 49.0,
+    // B=64 T=256 51.0 / 57.5, B=96 79.0 / 73.8.  TTSX_SPLIT=1 forces it wherever it is possible.
+    const bool pays = d->Bpad <= 32 || (d->Bpad == 64 && T > 128) || (e && e[0] == '1');
+    d->split = (B <= GEMV_MAX_B || (d->fused && pays)) && !(e && e[0] == '0') && !d->variant && !graves;
   }
   d->parity0 = 0;
   const size_t cb = d->Bpad;
