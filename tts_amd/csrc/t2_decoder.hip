@@ -364,7 +364,10 @@ __device__ __forceinline__ const float* seg_ptr(const Seg& sg, int parity) {
 // (every workgroup re-reads its 16*NT columns of the whole K range through the vector cache; the
 // weight stream costs next to nothing beside it), hence R = 2 for the LSTMs: one activation load
 // feeds two row blocks.
-template <int R, int NT, int KGW, int MODE>
+// DYN: the combine buffer lives in the launch's dynamic LDS instead of a static array (for pieces that share a
+// launch with the fused attention kernel: its ~55 KB of dynamic LDS are unused by the piece workgroups, and a
+// second 32 KB static array would push the launch past two workgroups per CU).
+template <int R, int NT, int KGW, int MODE, bool DYN = false>
 struct GemmOp {
   typedef GemmP P;
   static __device__ __forceinline__ void run(const GemmP& p, int wg_in) {
@@ -387,7 +390,14 @@ struct GemmOp {
     constexpr int DMAX = (R * NT >= 4) ? TTSX_DMAX_BIG : (NT == 1 && R == 1 ? 8 : 6);
     constexpr int D = KGW < DMAX ? KGW : DMAX;
     constexpr int TILES = R * NT, TPW = (TILES + GEMM_WAVES - 1) / GEMM_WAVES;
-    __shared__ f32x4 red[GEMM_WAVES][TILES][64];
+    f32x4(*red)[TILES][64];
+    if constexpr (DYN) {
+      extern __shared__ float4 gemm_dyn_lds[];
+      red = reinterpret_cast<f32x4(*)[TILES][64]>(gemm_dyn_lds);
+    } else {
+      __shared__ f32x4 red_s[GEMM_WAVES][TILES][64];
+      red = red_s;
+    }
 
     const float4* W =
         reinterpret_cast<const float4*>(p.Wp) + ((size_t)rb * p.kg_stride + p.kg0 + kbase + wave) * 64 + lane;
@@ -1100,7 +1110,10 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 
 constexpr int FA_TMAX = 512, FA_CF_PITCH = 36, FA_SA_LEN = FA_TMAX + 48;
 constexpr int FA_LDS_FLOATS = 2048 + 4096 + 2 * FA_SA_LEN + GEMM_WAVES * 16 * FA_CF_PITCH + 512 + 128 + 128 + 2 * FA_TMAX;
-template <int NTT, int EDIM>
+// PRE: encoder rows per thread that are requested ahead of the context phase (0: all of them at one tile per
+// wave, else 16).  With all 32 in flight the kernel needs 194 registers and its launch runs one workgroup per
+// CU; PRE = 16 brings it to 119, so that LSTM pieces sharing the launch can run two workgroups per CU.
+template <int NTT, int EDIM, int PRE = 0>
 struct FusedAttnOp {
   typedef AttnP P;
   static __device__ __forceinline__ void run(const AttnP& p, int wg) {
@@ -1180,7 +1193,7 @@ struct FusedAttnOp {
     constexpr int LPR = EDIM / 4, RG = CTX_THREADS / LPR;
     const int cl = tid % LPR, rg = tid / LPR;
     const float4* e4 = reinterpret_cast<const float4*>(p.enc + (size_t)b * T * EDIM) + cl;
-    constexpr int FA_PRE = NTT == 1 ? 128 / RG : 16;  // (more tiles per wave leave fewer registers free)
+    constexpr int FA_PRE = PRE ? PRE : (NTT == 1 ? 128 / RG : 16);  // (more tiles per wave leave fewer registers free)
     float4 pre[FA_PRE];
     const int t_last = max(len - 1, 0);
     constexpr int PRE_DT = FA_PRE / 8;  // loads per d-tile
@@ -1285,7 +1298,7 @@ struct FusedAttnOp {
       const float a0 = t < len ? s_al[t] : 0.f;
       acc.x += a0 * pre[i].x, acc.y += a0 * pre[i].y, acc.z += a0 * pre[i].z, acc.w += a0 * pre[i].w;
     }
-    if (NTT > 1) {
+    if (FA_PRE < 128 * NTT / RG) {
       // the remaining positions, in batches of independent row loads
 #pragma unroll 1
       for (int base = FA_PRE; base < 128 * NTT / RG; base += FA_PRE) {
@@ -1658,9 +1671,21 @@ struct Partial {
 // PK = k-groups per wave of the partial piece (12: attention LSTM, 16: decoder LSTM).  On the MFMA engine the
 // pieces are cut along K instead of into narrow tiles (32 x 32 tiles keep the activation re-reads down, and half
 // the K range keeps a piece workgroup short enough to pack into the CUs that op A leaves idle).
+template <class A>
+struct piece_in_dyn_lds {
+  static constexpr bool value = false;
+};
+template <int NTT, int EDIM, int PRE>
+struct piece_in_dyn_lds<FusedAttnOp<NTT, EDIM, PRE>> {
+  static constexpr bool value = true;
+};
+
 template <class A, int PK>
 int launch_with_piece(const ttsx_t2_decoder* d, const typename A::P& pa, int na, size_t smem, const Piece* pc,
                       hipStream_t st) {
+  constexpr bool DYN = piece_in_dyn_lds<A>::value;
+  static_assert(sizeof(f32x4) * GEMM_WAVES * 4 * 64 <= sizeof(float) * FA_LDS_FLOATS,
+                "the combine buffer of a 2 x 2 tile must fit the fused attention kernel's dynamic LDS");
   if (!pc || !pc->on) {
     dual_kernel<A, NoOp><<<na, GEMM_THREADS, smem, st>>>(pa, 0, na);
   } else if (d->B <= GEMV_MAX_B) {
@@ -1672,10 +1697,10 @@ int launch_with_piece(const ttsx_t2_decoder* d, const typename A::P& pa, int na,
     const int nt = d->Bpad / 16;
     if (nt % 2 == 0 && pc->g.nrb % 2 == 0) {
       const int nb = pc->g.nrb / 2 * (nt / 2) * pc->nk;
-      dual_kernel<A, GemmOp<2, 2, PK / 2, MODE_PARTIAL>><<<na + nb, GEMM_THREADS, smem, st>>>(pa, pc->g, na);
+      dual_kernel<A, GemmOp<2, 2, PK / 2, MODE_PARTIAL, DYN>><<<na + nb, GEMM_THREADS, smem, st>>>(pa, pc->g, na);
     } else {
       const int nb = pc->g.nrb * nt * pc->nk;
-      dual_kernel<A, GemmOp<1, 1, PK / 2, MODE_PARTIAL>><<<na + nb, GEMM_THREADS, smem, st>>>(pa, pc->g, na);
+      dual_kernel<A, GemmOp<1, 1, PK / 2, MODE_PARTIAL, DYN>><<<na + nb, GEMM_THREADS, smem, st>>>(pa, pc->g, na);
     }
   }
   TTSX_LAUNCH_CHECK();
@@ -1762,14 +1787,15 @@ hipError_t set_fused_lds_for() {
                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes)) != hipSuccess) return e;
   if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(dual_kernel<A, GemvOp<2, PK2, MODE_PARTIAL>>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes)) != hipSuccess) return e;
-  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(dual_kernel<A, GemmOp<1, 1, PK2 / 2, MODE_PARTIAL>>),
+  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(dual_kernel<A, GemmOp<1, 1, PK2 / 2, MODE_PARTIAL, true>>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes)) != hipSuccess) return e;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(dual_kernel<A, GemmOp<2, 2, PK2 / 2, MODE_PARTIAL>>),
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(dual_kernel<A, GemmOp<2, 2, PK2 / 2, MODE_PARTIAL, true>>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 hipError_t set_fused_lds() {
   hipError_t e = set_fused_lds_for<FusedAttnOp<1, ENC_DIM>>();
   if (e != hipSuccess) return e;
+  if ((e = set_fused_lds_for<FusedAttnOp<1, ENC_DIM, 16>>()) != hipSuccess) return e;
   if ((e = set_fused_lds_for<FusedAttnOp<2, ENC_DIM>>()) != hipSuccess) return e;
   return set_fused_lds_for<FusedAttnOp<4, ENC_DIM>>();
 }
@@ -1879,7 +1905,8 @@ int enqueue_step(ttsx_t2_decoder* d, int i, bool first, bool more, hipStream_t s
     pc = Piece{pd.g, split};
     pc.g.rb0 = 0, pc.g.nrb = pd.total_rb, pc.nk = pd.g.kparts;
     const size_t smem = sizeof(float) * FA_LDS_FLOATS;
-    if (T <= 128) rc = launch_with_piece<FusedAttnOp<1, ENC_DIM>, PK2>(d, ap, B, smem, &pc, st);
+    if (T <= 128 && split && Bpad >= 64) rc = launch_with_piece<FusedAttnOp<1, ENC_DIM, 16>, PK2>(d, ap, B, smem, &pc, st);
+    else if (T <= 128) rc = launch_with_piece<FusedAttnOp<1, ENC_DIM>, PK2>(d, ap, B, smem, &pc, st);
     else if (T <= 256) rc = launch_with_piece<FusedAttnOp<2, ENC_DIM>, PK2>(d, ap, B, smem, &pc, st);
     else rc = launch_with_piece<FusedAttnOp<4, ENC_DIM>, PK2>(d, ap, B, smem, &pc, st);
     if (rc) return rc;
@@ -2191,9 +2218,9 @@ extern "C" int ttsx_t2_decoder_begin(ttsx_t2_decoder* d, const float* enc, const
     // On the MFMA engine the split needs the fused attention launch (one CU per utterance busy for ~11 us: the
     // shadow the early decoder-LSTM columns run in; the three-launch attention fills the chip itself), and it
     // pays while the pieces fit into that shadow.  Measured per step, split / whole LSTM launches (T=128 unless
-    // noted): B=4 34.1 / 37.2 us, B=16 33.7 / 37.4, B=32 38.2 / 41.0, B=32 T=256 45.2 / 48.8, B=64 50.3 / 49.0,
-    // B=64 T=256 51.0 / 57.5, B=96 79.0 / 73.8.  TTSX_SPLIT=1 forces it wherever it is possible.
-    const bool pays = d->Bpad <= 32 || (d->Bpad == 64 && T > 128) || (e && e[0] == '1');
+    // noted): B=4 34.1 / 37.2 us, B=16 33.7 / 37.4, B=32 38.2 / 41.0, B=32 T=256 45.2 / 48.8, B=64 T=64 48.1 / 47.6,
+    // B=64 48.1 / 49.1, B=64 T=200 50.4 / 56.7, B=96 75.0 / 73.6.  TTSX_SPLIT=1 forces it wherever it is possible.
+    const bool pays = d->Bpad <= 32 || (d->Bpad == 64 && T > 64) || (e && e[0] == '1');
     d->split = (B <= GEMV_MAX_B || (d->fused && pays)) && !(e && e[0] == '0') && !d->variant && !graves;
   }
   d->parity0 = 0;
