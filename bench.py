@@ -237,7 +237,7 @@ def main():
             roof["traffic"] = pmc["hbm_bytes_per_step"]
             roof["traffic_source"] = "profiles/r1_decoder_pmc.csv"
     roof["kernel"] = ("t2 decoder step (5 launches: prenet-2, attention LSTM + query shares, fused attention, "
-                      "decoder LSTM, projection)")
+                      "decoder LSTM, projection; the early LSTM columns ride along as partial pieces)")
     roof["us_per_launch_group"] = dec_us
     roof["algorithmic_bytes"] = nbytes
     roof["algorithmic_flops"] = flops
