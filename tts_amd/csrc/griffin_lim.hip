@@ -263,16 +263,13 @@ __device__ __forceinline__ void frame_body(const FrameP& p, int b, int i, float2
       W8[c] = s_tw2[k + z];
     }
 #pragma unroll
-    for (int c = 0; c < 9; ++c) {
-      int k;
-      if (c < 8) k = lane_b + 64 * c;
-      else if (lane_b == 0) k = 512;
-      else break;
+    for (int c = 0; c < 8; ++c) {
+      const int k = lane_b + 64 * c;
       const int mkk = MC - k;  // partner bin (1024 for k = 0)
-      const float2 W = c < 8 ? W8[c < 8 ? c : 0] : s_tw2[512 + z];
+      const float2 W = W8[c];
       float2 Xk, Xm;
       if (KIND == K_GL_ITER || KIND == K_STFT) {
-        const float2 Zk = c < 8 ? Zk8[c < 8 ? c : 0] : s[pidx(512)], Zm = c < 8 ? Zm8[c < 8 ? c : 0] : s[pidx(512)];
+        const float2 Zk = Zk8[c], Zm = Zm8[c];
         const float2 E = make_float2(0.5f * (Zk.x + Zm.x), 0.5f * (Zk.y - Zm.y));
         const float2 D = make_float2(0.5f * (Zk.x - Zm.x), 0.5f * (Zk.y + Zm.y));  // (Zk - conj(Zm))/2
         const float2 O = make_float2(D.y, -D.x);                                  // -i * D
@@ -289,7 +286,7 @@ __device__ __forceinline__ void frame_body(const FrameP& p, int b, int i, float2
 #ifdef EXP_NOMAG
       if (KIND == K_GL_ITER || KIND == K_GL_INIT) sk = 1.f + z, sm = 2.f + z;
 #else
-      if (KIND == K_GL_ITER) sk = c < 8 ? mk[c < 8 ? c : 0] : m512, sm = c < 8 ? mm[c < 8 ? c : 0] : m512;
+      if (KIND == K_GL_ITER) sk = mk[c], sm = mm[c];
       if (KIND == K_GL_INIT) sk = mg[k], sm = mg[mkk];
 #endif
       if (KIND == K_GL_ITER) {
@@ -316,6 +313,28 @@ __device__ __forceinline__ void frame_body(const FrameP& p, int b, int i, float2
       // (k = 0 has no partner slot: it stores its own value a second time, which keeps the store unconditional
       // and the eight pairs in one basic block)
       s[pidx(k ? mkk : 0)] = k ? zm : zk;
+    }
+    if (lane_b == 0) {
+      // Bin 512 is its own partner and its twiddle W_2048^512 is -i: the post-pass of the real transform reduces
+      // to X[512] = conj(Z[512]) and the pre-pass of the inverse to Z'[512] = conj(X'[512]).
+      float2 X = make_float2(0.f, 0.f);
+      if (KIND == K_GL_ITER || KIND == K_STFT) X = cconj(s[pidx(512)]);
+      if (KIND == K_STFT) {
+        p.spec_re[frow * NBIN + 512] = X.x, p.spec_im[frow * NBIN + 512] = X.y;
+      } else {
+        if (KIND == K_GL_ITER) {
+          const float2 u = unit_phase(X);
+          X = make_float2(m512 * u.x, m512 * u.y);
+        } else if (KIND == K_GL_INIT) {
+          float sn, cs;
+          sincospif(2.0f * p.phase01[frow * NBIN + 512], &sn, &cs);
+          const float sk = mg[512];
+          X = make_float2(sk * cs, sk * sn);
+        } else {  // K_ISTFT
+          X = make_float2(p.spec_re[frow * NBIN + 512], p.spec_im[frow * NBIN + 512]);
+        }
+        s[pidx(512)] = cconj(X);
+      }
     }
     if (KIND == K_STFT) return;
 
