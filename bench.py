@@ -182,7 +182,7 @@ def main():
     p.add_argument("--t-in", type=int, default=128)
     p.add_argument("--dec-steps", type=int, default=800)
     p.add_argument("--r", type=int, default=1)
-    p.add_argument("--cpu-sample-steps", type=int, default=600)
+    p.add_argument("--cpu-sample-steps", type=int, default=1600)  # ~11 s of host work
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-batch1", action="store_true")
     a = p.parse_args()
