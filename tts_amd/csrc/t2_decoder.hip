@@ -1762,14 +1762,15 @@ hipError_t set_context_lds_for(size_t bytes) {
   return hipFuncSetAttribute(reinterpret_cast<const void*>(dual_kernel<ContextOp<32>, B>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
-hipError_t set_context_lds(size_t bytes) {
+hipError_t set_context_lds(size_t bytes, bool variant, bool graves) {
   hipError_t e;
-  // the one-workgroup-per-utterance variants keep up to three rows of T floats
-  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(dual_kernel<AttnPostOp, NoOp>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(3 * bytes))) != hipSuccess)
+  // the one-workgroup-per-utterance variants keep up to three rows of T floats (only asked for when they run:
+  // at the longest texts of the plain attention that request would exceed the LDS of a CU)
+  if (variant && (e = hipFuncSetAttribute(reinterpret_cast<const void*>(dual_kernel<AttnPostOp, NoOp>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)(3 * bytes))) != hipSuccess)
     return e;
-  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(dual_kernel<GravesOp, NoOp>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * bytes + 64))) != hipSuccess)
+  if (graves && (e = hipFuncSetAttribute(reinterpret_cast<const void*>(dual_kernel<GravesOp, NoOp>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * bytes + 64))) != hipSuccess)
     return e;
   if ((e = set_context_lds_for<NoOp>(bytes)) != hipSuccess) return e;
   if ((e = set_context_lds_for<GemvOp<1, PK2, MODE_PARTIAL>>(bytes)) != hipSuccess) return e;
@@ -2257,7 +2258,7 @@ extern "C" int ttsx_t2_decoder_begin(ttsx_t2_decoder* d, const float* enc, const
   TTSX_LAUNCH_CHECK();
   d->keep_next = false, d->mem0_set = false;
   if (3 * sizeof(float) * T > 48 * 1024) {
-    TTSX_HIP(set_context_lds(sizeof(float) * T));
+    TTSX_HIP(set_context_lds(sizeof(float) * T, d->variant, graves));
   }
   TTSX_HIP(hipMemcpyAsync(d->enc_ws, enc, sizeof(float) * (size_t)B * T * ENC_DIM, hipMemcpyDeviceToDevice, st));
   fill_len_kernel<<<ceil_div(B, 256), 256, 0, st>>>(d->len_ws, enc_len, B, T);
