@@ -157,3 +157,44 @@ def test_griffin_lim_is_scale_invariant_over_the_float_range():
         assert _snr_db(y, ys.astype(np.float64) / float(c)) >= 60.0, e
     z = ap._griffin_lim(np.zeros_like(S), init_phase=ph)
     assert np.array_equal(z, np.zeros_like(z))
+
+
+@pytest.mark.parametrize("hop,win,v1", [(137, 1096, False), (1100, 1100, False), (64, 512, False), (551, 1101, True),
+                                        (300, 1102, True), (1, 2, False)])
+def test_stft_geometries_at_the_limits(hop, win, v1):
+    """Window / hop combinations at the edges of what the entry points accept: eight overlapping frames per
+    sample, no overlap at all (hop = win: no carry between rounds), a short window, an odd window with odd left
+    padding, the longest window (1102), the shortest (2); STFT, ISTFT and a short Griffin-Lim run against the
+    oracle.  (sample_rate = 1000 makes milliseconds equal samples.)"""
+    from oracle import audio_oracle as ao
+    from tts_amd import synthetic
+    from tts_amd.audio import AudioProcessor
+    cfg = dict(ao.T1_AUDIO if v1 else ao.T2_AUDIO, sample_rate=1000, frame_shift_ms=float(hop),
+               frame_length_ms=float(win), mel_fmin=0.0, mel_fmax=None, griffin_lim_iters=4)
+    orc = ao.AudioOracle(**cfg)
+    ap = AudioProcessor(tacotron_v1=v1, verbose=False,
+                        **{k: v for k, v in cfg.items() if k not in ("pad_mode", "win_from_hop")})
+    assert (ap.hop_length, ap.win_length) == (orc.hop_length, orc.win_length) == (hop, win)
+    F = max(9, 1100 // hop + 6) if hop > 1 else 1500        # (reflect padding needs more than n_fft/2 samples)
+    rng = np.random.default_rng(hop * 7 + win)
+    y = (rng.standard_normal(hop * (F - 1)) * 0.3).astype(np.float32)
+    X_ref = orc._stft(y)
+    X = ap._stft(y)
+    assert X.shape == X_ref.shape == (1025, F)
+    assert np.abs(X - X_ref).max() < 1e-4 * max(1.0, np.abs(X_ref).max())
+    y_ref = orc._istft(X_ref.astype(np.complex128))
+    y_got = ap._istft(X_ref)
+    assert y_got.shape == y_ref.shape
+    d = np.abs(y_got - y_ref) / max(1.0, np.abs(y_ref).max())
+    if hop == win:
+        # no overlap: next to the frame boundaries the signal is (x w^2) / w^2 with w^2 down to 1e-11, where fp32
+        # and the oracle's fp64 part ways by construction; everywhere else the usual bar holds
+        assert np.quantile(d, 0.75) < 1e-5 and d.max() < 5e-2   # (w^2 < 1e-2 on a fifth of each frame)
+    else:
+        assert d.max() < 1e-5
+    S = np.abs(X_ref).astype(np.float32)
+    ph = synthetic.gl_init_phase(11, 1025, F)
+    g_ref = orc._griffin_lim(S, ph)
+    g = ap._griffin_lim(S, init_phase=ph)
+    assert g.shape == g_ref.shape
+    assert _snr_db(g_ref, g) >= 40.0
