@@ -110,3 +110,29 @@ def test_entry_points_reject_bad_arguments_before_any_device_call():
     assert lib.ttsx_griffin_lim(one, one, None, 1, 8, byref(sp), -1, 1.0, one, None) == _lib.ERR_ARG
     assert lib.ttsx_postnet_run(one, one, None, 0, 8, one, None) == _lib.ERR_ARG    # empty batch
     assert lib.ttsx_encoder_convs_run(one, one, None, 1, 0, one, None) == _lib.ERR_ARG   # empty text
+
+
+def test_header_is_plain_c_and_links_from_a_c_host(tmp_path):
+    """include/ttsx.h compiles as C99 (-pedantic) and a C program linked against libttsx.so can call it: the
+    boundary is a C ABI, not a C++ or Python one."""
+    import shutil
+    import subprocess
+    from tts_amd import _lib
+    if shutil.which("gcc") is None:
+        import pytest
+        pytest.skip("no gcc")
+    src = tmp_path / "host.c"
+    src.write_text('#include <stdio.h>\n#include "ttsx.h"\n'
+                   "int main(void) {\n"
+                   "  int rc = ttsx_postnet_run(NULL, NULL, NULL, 1, 1, NULL, NULL);\n"
+                   '  printf("%d %d %s\\n", ttsx_version(), rc, ttsx_last_error_string());\n'
+                   "  return rc == TTSX_ERR_ARG ? 0 : 1;\n}\n")
+    exe = tmp_path / "host"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    cc = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
+                         str(src), "-L", libdir, "-lttsx", "-Wl,-rpath," + libdir, "-o", str(exe)],
+                        capture_output=True, text=True)
+    assert cc.returncode == 0, cc.stderr
+    run = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert run.returncode == 0, run.stdout + run.stderr
+    assert "ttsx_postnet_run" in run.stdout
