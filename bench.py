@@ -296,6 +296,15 @@ def main():
                            "decoder_us_per_step": sL["decoder"] * 1e3 / 2000}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(sd, T, a.cpu_sample_steps, r)
+        # the same path on one host thread (a quarter of the sample), as a scalar reference point
+        nt = torch.get_num_threads()
+        torch.set_num_threads(1)
+        try:
+            one = cpu_baseline(sd, T, max(a.cpu_sample_steps // 4, 8), r)
+        finally:
+            torch.set_num_threads(nt)
+        out["cpu_baseline"]["one_thread"] = {"value": one["value"], "unit": one["unit"], "cores": 1,
+                                             "sample": one["sample"]}
     else:
         out["cpu_baseline"] = None
     if rank == 0:
