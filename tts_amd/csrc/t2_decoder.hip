@@ -13,7 +13,11 @@
 //
 // Launches per step (captured into a hipGraph per chunk of steps):
 //   prenet layer 2 | attention LSTM | query | energies | normalise+context | decoder LSTM | projection
-// Each LSTM is cut in two along K.  The columns whose inputs are known early (attention LSTM:
+// or, for texts short enough for one workgroup per utterance (FusedAttnOp),
+//   prenet layer 2 | attention LSTM (+ its shares of the query projection) | fused attention | decoder LSTM |
+//   projection.
+// Each LSTM can be cut in two along K (always at batch 1-2; on the MFMA engine where it measured faster, see
+// ttsx_t2_decoder_begin).  The columns whose inputs are known early (attention LSTM:
 // previous context and hidden state; decoder LSTM: new attention hidden state and own previous
 // hidden state) are multiplied by "partial" work that leaves raw gate sums in a buffer; the launch
 // on the serial path only adds the late columns (prenet output, 256; new context, 512) and applies
@@ -22,6 +26,8 @@
 // are dealt out in three pieces that ride along in the same launches as those small kernels
 // (a launch = workgroups of the small op first, then workgroups of a partial piece): the heavy
 // streaming runs in the shadow of the serial chain without any cross-stream synchronisation.
+// (On the MFMA engine the pieces are 32 x 32 tiles over two halves of the early K range, with one gate-sum
+// buffer per half.)
 // The projection launch carries, besides the 80*r_init mel rows, two sets of composed rows so
 // that nothing else sits on the serial path between two steps:
 //   * one row  u = [w_s,h + W_o,h^T w_s,o ; W_o,c^T w_s,o]  whose product with [h_d; ctx] is the
