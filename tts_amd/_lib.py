@@ -5,7 +5,7 @@ caller gets an exception.
 """
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_long, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_long, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, os.environ.get("TTSX_LIB", "libttsx.so"))
