@@ -19,6 +19,7 @@
 // The stand-alone STFT / ISTFT entry points use the same frame code with a separate
 // overlap-add launch.
 #include <math.h>
+#include <stdlib.h>
 
 #include <mutex>
 #include <vector>
@@ -822,7 +823,8 @@ extern "C" int ttsx_griffin_lim(const float* mag, const float* init_phase, const
   P.carry_len = q.win - q.hop;
   // rounds per workgroup: long runs amortise the halo, short ones fill the chip (3 workgroups per CU)
   // (as many workgroups as fit on the chip at once, so that no second, mostly empty wave of them runs)
-  P.C = std::max(1, ceil_div(P.n_rounds, std::max(1, 256 * 3 / B)));
+  static const int wgs_per_cu = getenv("TTSX_GL_WGS_PER_CU") ? atoi(getenv("TTSX_GL_WGS_PER_CU")) : 3;
+  P.C = std::max(1, ceil_div(P.n_rounds, std::max(1, 256 * wgs_per_cu / B)));
   const dim3 grid(ceil_div(P.n_rounds, P.C), B), refl_grid(NFFT / 256, B);
   const size_t smem = 2 * (size_t)std::max(P.carry_len, 1) * sizeof(float);
   const bool reflect = sp->pad_mode == TTSX_PAD_REFLECT;
