@@ -95,3 +95,35 @@ def test_batched_request_equals_sentence_by_sentence():
     err = a.astype(np.float64) - b.astype(np.float64)
     snr = 10 * np.log10((a.astype(np.float64) ** 2).sum() / max((err ** 2).sum(), 1e-300))
     assert snr > 50.0, snr
+
+
+def test_handles_release_their_device_memory():
+    """Building, running and dropping both models several times leaves the free device memory where it was
+    (within the allocator's slack): create / destroy pairs release the packed weights, workspaces and graphs."""
+    import gc
+    from tts_amd import synthetic
+    from tts_amd.tacotron import Tacotron
+    from tts_amd.tacotron2 import Tacotron2
+
+    def cycle():
+        m = Tacotron2(num_chars=129, num_speakers=0, r=7, attn_norm="sigmoid", prenet_type="bn", prenet_dropout=False,
+                      separate_stopnet=True)
+        m.load_state_dict(synthetic.t2_state_dict(seed=0, gains={"stop_bias": -30.0}))
+        m.cuda().eval()
+        m.inference_batch(torch.as_tensor(synthetic.t2_text_ids(3, 4, 30)), fixed_steps=3)
+        v = Tacotron(61, 256, 1025, 80, 2, None, 5)
+        v.load_state_dict(synthetic.t1_state_dict(seed=0))
+        v.cuda().eval()
+        v.decoder.max_decoder_steps = 3
+        v.forward(torch.as_tensor(synthetic.t1_text_ids(1, 20)).cuda())
+        del m, v
+        gc.collect()
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+
+    cycle()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(4):
+        cycle()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < 64 << 20, "leaked %.1f MB over four create/destroy cycles" % ((free0 - free1) / 2 ** 20)
