@@ -127,3 +127,53 @@ def test_handles_release_their_device_memory():
         cycle()
     free1 = torch.cuda.mem_get_info()[0]
     assert free0 - free1 < 64 << 20, "leaked %.1f MB over four create/destroy cycles" % ((free0 - free1) / 2 ** 20)
+
+
+def test_two_request_threads_with_their_own_models():
+    """Two host threads, each with its own model handle and stream, sharing one AudioProcessor (whose vocoder
+    calls serialise on the library's scratch lock): every result equals the one the same model gives alone."""
+    import threading
+    from tts_amd import synthetic
+    from tts_amd.audio import AudioProcessor
+    from tts_amd.tacotron2 import Tacotron2
+    from oracle import audio_oracle as ao
+    kw = {k: v for k, v in ao.T2_AUDIO.items() if k not in ("pad_mode", "win_from_hop")}
+    kw["griffin_lim_iters"] = 5
+    ap = AudioProcessor(verbose=False, **kw)
+    models, ids = [], []
+    for s in range(2):
+        m = Tacotron2(num_chars=129, num_speakers=0, r=7, attn_norm="sigmoid", prenet_type="bn", prenet_dropout=False,
+                      separate_stopnet=True)
+        m.load_state_dict(synthetic.t2_state_dict(seed=s, gains={"stop_bias": -30.0}))
+        m.cuda().eval()
+        m.decoder.set_r(2)
+        models.append(m)
+        ids.append(torch.as_tensor(synthetic.t2_text_ids(40 + s, 1, 30 + 11 * s)))
+    phase = [synthetic.gl_init_phase(60 + s, 1025, 24) for s in range(2)]
+
+    def request(s):
+        o = models[s].inference_batch(ids[s], fixed_steps=12)
+        mel = o["postnet_output"][0].cpu().numpy().T
+        return mel, ap.inv_mel_spectrogram(mel, init_phase=phase[s])
+
+    alone = [request(s) for s in range(2)]
+    got, errs = [[None] * 4 for _ in range(2)], []
+
+    def worker(s):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream()):
+                for k in range(4):
+                    got[s][k] = request(s)
+        except Exception as e:   # surfaced below: an exception in a thread would otherwise pass silently
+            errs.append(e)
+
+    th = [threading.Thread(target=worker, args=(s,)) for s in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    for s in range(2):
+        for k in range(4):
+            np.testing.assert_array_equal(got[s][k][0], alone[s][0])
+            np.testing.assert_array_equal(got[s][k][1], alone[s][1])
