@@ -703,10 +703,30 @@ struct EnergyOp {
     const int t = t0 + tg * EN_DP + i;
     pin[i] = t < T ? p.P[((size_t)b * T + t) * ATT_DIM + d] : 0.f;
   }
-  const float qd = p.q[qidx(d, b, p.Bpad)], vd = p.v_w[d], vb = p.v_b[0];
+  const float vd = p.v_w[d], vb = p.v_b[0];
+  // The query either comes from the query launch, or (p.qpart) as the shares the attention-LSTM workgroups left:
+  // thread (d, tg) adds the groups tg, tg + 4, ... (every load issued before the first use; clamped and masked,
+  // not conditional), the four partial sums meet in LDS in a fixed order.
+  __shared__ float s_qs[4][ATT_DIM];
+  float qd = 0.f;
+  if (p.qpart) {
+    constexpr int QU = QUERY_DIM / 4 / 4;  // at most 256 groups
+    const float* qp = p.qpart + (size_t)b * ATT_DIM + d;
+    const size_t gs = (size_t)p.Bpad * ATT_DIM;
+    float qv[QU];
+#pragma unroll
+    for (int u = 0; u < QU; ++u) qv[u] = qp[(size_t)min(tg + 4 * u, p.n_qgroups - 1) * gs];
+    float acc = 0.f;
+#pragma unroll
+    for (int u = 0; u < QU; ++u) acc += tg + 4 * u < p.n_qgroups ? qv[u] : 0.f;
+    s_qs[tg][d] = acc;
+  } else {
+    qd = p.q[qidx(d, b, p.Bpad)];
+  }
 
   if (tid < 2 * (EN_TT + 2 * ATT_PAD)) s_a[tid / (EN_TT + 2 * ATT_PAD)][tid % (EN_TT + 2 * ATT_PAD)] = a_in;
   __syncthreads();
+  if (p.qpart) qd = ((s_qs[0][d] + s_qs[1][d]) + (s_qs[2][d] + s_qs[3][d])) + (p.q_bias ? p.q_bias[d] : 0.f);
   {
     float acc[EN_CP];
 #pragma unroll
@@ -1507,6 +1527,7 @@ struct ttsx_t2_decoder {
   hipGraphExec_t graph;
   hipStream_t cap_stream;  // capture-only stream: the caller's stream may be the legacy default stream
   int g_B, g_T, g_r, g_gen, g_chunk, g_split, g_fused;
+  bool share_q;  // three-launch attention without the query launch: the energies op adds up the query shares
 };
 
 namespace {
@@ -1872,7 +1893,7 @@ int enqueue_step(ttsx_t2_decoder* d, int i, bool first, bool more, hipStream_t s
   g.seg[1] = Seg{{d->ctx, nullptr}, 0, ENC_DIM / 16};
   g.seg[2] = Seg{{d->h_a[0], d->h_a[1]}, 1, QUERY_DIM / 16};
   g.out[0] = d->h_a[0], g.out[1] = d->h_a[1], g.c = d->c_a, g.relu = 0;
-  if (d->fused) g.wq_t = d->wq_t, g.qpart = d->qpart;  // the launch also leaves the shares of the query
+  if (d->fused || d->share_q) g.wq_t = d->wq_t, g.qpart = d->qpart;  // the launch also leaves the shares of the query
   if (split) {
     g.nseg = 1, g.KG = PRENET_DIM / 16, g.gates = d->g_a;
     g.kparts = pa.g.kparts, g.gates_part_stride = pa.g.gates_part_stride;
@@ -1918,6 +1939,11 @@ int enqueue_step(ttsx_t2_decoder* d, int i, bool first, bool more, hipStream_t s
     else rc = launch_with_piece<FusedAttnOp<4, ENC_DIM>, PK2>(d, ap, B, smem, &pc, st);
     if (rc) return rc;
   } else {
+  const bool share_q = d->share_q;
+  if (share_q) {
+    // no query launch: the energies op sums the shares   (decoder partial in two halves instead of three thirds)
+    ap.qpart = d->qpart, ap.n_qgroups = d->qpart_groups;
+  } else {
   // query projection   (+ first third of the decoder partial)
   g.Wp = d->w_query, g.bias = d->b_query, g.nseg = 1, g.KG = QUERY_DIM / 16, g.kg0 = 0, g.kg_stride = g.KG;
   g.gates = nullptr;
@@ -1926,8 +1952,9 @@ int enqueue_step(ttsx_t2_decoder* d, int i, bool first, bool more, hipStream_t s
   pc = pd.piece(0);
   pc.on = split;
   if ((rc = launch_gemm<MODE_LINEAR, 8, PK2>(d, g, ATT_DIM / 16, false, &pc, st))) return rc;
+  }
   // attention   (+ second and last third of the decoder partial)
-  pc = pd.piece(1);
+  pc = share_q ? pd.piece(0, 2) : pd.piece(1);
   pc.on = split;
   if (B >= 16) {
     ap.gx = ceil_div(T, 32);
@@ -1937,7 +1964,7 @@ int enqueue_step(ttsx_t2_decoder* d, int i, bool first, bool more, hipStream_t s
     rc = launch_with_piece<EnergyOp<16>, PK2>(d, ap, ap.gx * B, 0, &pc, st);
   }
   if (rc) return rc;
-  pc = pd.piece(2);
+  pc = share_q ? pd.piece(1, 2) : pd.piece(2);
   pc.on = split;
   if (d->variant) {
     // windowing / forward attention: the whole tail of an utterance in one workgroup
@@ -1991,7 +2018,7 @@ int push_ctx(ttsx_t2_decoder* d, hipStream_t st) {
 // Launch `n` steps as one graph (captured once per (B, T, r, workspace) and chunk size).
 int launch_chunk(ttsx_t2_decoder* d, int n, hipStream_t st) {
   const bool cached = d->graph && d->g_B == d->B && d->g_T == d->T && d->g_r == d->rc_host->r &&
-                      d->g_gen == d->ws_gen && d->g_chunk == n && d->g_split == (int)d->split &&
+                      d->g_gen == d->ws_gen && d->g_chunk == n && d->g_split == (int)d->split + 2 * (int)d->share_q &&
                       d->g_fused == (int)d->fused;
   if (!cached && n == CHUNK) {
     drop_graph(d);
@@ -2010,7 +2037,7 @@ int launch_chunk(ttsx_t2_decoder* d, int n, hipStream_t st) {
     TTSX_HIP(hipGraphInstantiate(&d->graph, graph, nullptr, nullptr, 0));
     (void)hipGraphDestroy(graph);
     d->g_B = d->B, d->g_T = d->T, d->g_r = d->rc_host->r, d->g_gen = d->ws_gen, d->g_chunk = n;
-    d->g_split = d->split, d->g_fused = d->fused;
+    d->g_split = (int)d->split + 2 * (int)d->share_q, d->g_fused = d->fused;
   }
   if (n == CHUNK) {
     TTSX_HIP(hipGraphLaunch(d->graph, st));
@@ -2222,6 +2249,10 @@ extern "C" int ttsx_t2_decoder_begin(ttsx_t2_decoder* d, const float* enc, const
     const char* f = getenv("TTSX_FUSED_ATTN");
     const int t_max = B >= 48 ? FA_TMAX : (B > GEMV_MAX_B || (f && f[0] == '1')) ? 256 : 128;
     d->fused = T <= t_max && !d->variant && !graves && !(f && f[0] == '0');
+    // Batch 1-2 without the fused kernel: the query launch is dropped and the energies workgroups add up the
+    // query shares themselves (TTSX_SHARE_Q=0: keep the query launch).
+    const char* sq = getenv("TTSX_SHARE_Q");
+    d->share_q = B <= GEMV_MAX_B && !d->fused && !d->variant && !graves && !(sq && sq[0] == '0');
     // On the MFMA engine the split needs the fused attention launch (one CU per utterance busy for ~11 us: the
     // shadow the early decoder-LSTM columns run in; the three-launch attention fills the chip itself), and it
     // pays while the pieces fit into that shadow.  Measured per step, split / whole LSTM launches (T=128 unless
