@@ -512,18 +512,25 @@ struct GemmOp {
 
 // GEMV engine for NB <= 2 utterances (Bpad == NB): every weight load of a wave is issued before
 // the first use, activations come from LDS.  KGW = k-groups per wave (KG / 8).
-template <int NB, int KGW, int MODE>
+// KP > 1 (PARTIAL pieces): the K range is cut into KP parts of KGW*8 k-groups and the launch runs one block of
+// workgroups per part (part k writes gates + k * gates_part_stride), so that a piece of a few row blocks still
+// spreads its weight stream over many CUs.
+template <int NB, int KGW, int MODE, int KP = 1>
 struct GemvOp {
   typedef GemmP P;
   static __device__ __forceinline__ void run(const GemmP& p, int wg) {
     const int done = p.ctx->all_done;
+    int kpart = 0;
+    if (KP > 1) kpart = wg / p.nrb, wg -= kpart * p.nrb, kpart += p.kpart0;
+    const int kbase = kpart * (KGW * GEMM_WAVES);
     const int rb = p.rb0 + wg, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, tid = threadIdx.x;
-    constexpr int KG = KGW * GEMM_WAVES;
+    constexpr int KG = KGW * GEMM_WAVES * KP;
     __shared__ float4 s_x[KG * 4 * NB];  // quad-interleaved: [quad][b]
     __shared__ float s_red[GEMM_WAVES][NB][16];
 
     // issue the weight stream first
-    const float4* W = reinterpret_cast<const float4*>(p.Wp) + ((size_t)rb * p.kg_stride + p.kg0) * 64 + lane;
+    const float4* W =
+        reinterpret_cast<const float4*>(p.Wp) + ((size_t)rb * p.kg_stride + p.kg0 + kbase) * 64 + lane;
     float4 wv[KGW];
 #pragma unroll
     for (int i = 0; i < KGW; ++i) wv[i] = W[(size_t)(wave + i * GEMM_WAVES) * 64];
@@ -560,7 +567,7 @@ struct GemvOp {
     const int kq = lane >> 4;
 #pragma unroll
     for (int i = 0; i < KGW; ++i) {
-      const int quad = (wave + i * GEMM_WAVES) * 4 + kq;
+      const int quad = (kbase + wave + i * GEMM_WAVES) * 4 + kq;
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
         const float4 xv = s_x[quad * NB + b];
@@ -585,7 +592,7 @@ struct GemvOp {
         for (int w = 0; w < GEMM_WAVES; ++w) t += s_red[w][eb][qi * 4 + j];
         v[j] = t;
       }
-      const float h = epilogue_quad<MODE>(p, quad_e, eb, v, pre);
+      const float h = epilogue_quad<MODE>(p, quad_e, eb, v, pre, kpart);
       if (MODE == MODE_LSTM || MODE == MODE_GRU) s_hq[qi][eb] = h;
     }
     if (qshare) {
@@ -1716,9 +1723,16 @@ int launch_with_piece(const ttsx_t2_decoder* d, const typename A::P& pa, int na,
   if (!pc || !pc->on) {
     dual_kernel<A, NoOp><<<na, GEMM_THREADS, smem, st>>>(pa, 0, na);
   } else if (d->B <= GEMV_MAX_B) {
-    const int nb = pc->g.nrb;
-    if (d->B == 1) dual_kernel<A, GemvOp<1, PK, MODE_PARTIAL>><<<na + nb, GEMM_THREADS, smem, st>>>(pa, pc->g, na);
-    else dual_kernel<A, GemvOp<2, PK, MODE_PARTIAL>><<<na + nb, GEMM_THREADS, smem, st>>>(pa, pc->g, na);
+    if (pc->g.kparts > 1) {
+      // both K parts of the piece's row blocks: twice the workgroups, half the stream each
+      const int nb = pc->g.nrb * 2;
+      if (d->B == 1) dual_kernel<A, GemvOp<1, PK / 2, MODE_PARTIAL, 2>><<<na + nb, GEMM_THREADS, smem, st>>>(pa, pc->g, na);
+      else dual_kernel<A, GemvOp<2, PK / 2, MODE_PARTIAL, 2>><<<na + nb, GEMM_THREADS, smem, st>>>(pa, pc->g, na);
+    } else {
+      const int nb = pc->g.nrb;
+      if (d->B == 1) dual_kernel<A, GemvOp<1, PK, MODE_PARTIAL>><<<na + nb, GEMM_THREADS, smem, st>>>(pa, pc->g, na);
+      else dual_kernel<A, GemvOp<2, PK, MODE_PARTIAL>><<<na + nb, GEMM_THREADS, smem, st>>>(pa, pc->g, na);
+    }
   } else {
     // K in two parts of PK/2 k-groups per wave, 32 x 32 tiles (16 x 16 when the batch is one column tile)
     const int nt = d->Bpad / 16;
@@ -1800,6 +1814,8 @@ hipError_t set_context_lds(size_t bytes, bool variant, bool graves) {
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * bytes + 64))) != hipSuccess)
     return e;
   if ((e = set_context_lds_for<NoOp>(bytes)) != hipSuccess) return e;
+  if ((e = set_context_lds_for<GemvOp<1, PK2 / 2, MODE_PARTIAL, 2>>(bytes)) != hipSuccess) return e;
+  if ((e = set_context_lds_for<GemvOp<2, PK2 / 2, MODE_PARTIAL, 2>>(bytes)) != hipSuccess) return e;
   if ((e = set_context_lds_for<GemvOp<1, PK2, MODE_PARTIAL>>(bytes)) != hipSuccess) return e;
   return set_context_lds_for<GemvOp<2, PK2, MODE_PARTIAL>>(bytes);
 }
@@ -1811,9 +1827,13 @@ hipError_t set_fused_lds_for() {
   hipError_t e;
   if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(dual_kernel<A, NoOp>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes)) != hipSuccess) return e;
+  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(dual_kernel<A, GemvOp<1, PK2 / 2, MODE_PARTIAL, 2>>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, bytes)) != hipSuccess) return e;
   if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(dual_kernel<A, GemvOp<1, PK2, MODE_PARTIAL>>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes)) != hipSuccess) return e;
   if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(dual_kernel<A, GemvOp<2, PK2, MODE_PARTIAL>>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, bytes)) != hipSuccess) return e;
+  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(dual_kernel<A, GemvOp<2, PK2 / 2, MODE_PARTIAL, 2>>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes)) != hipSuccess) return e;
   if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(dual_kernel<A, GemmOp<1, 1, PK2 / 2, MODE_PARTIAL, true>>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes)) != hipSuccess) return e;
@@ -1828,13 +1848,16 @@ hipError_t set_fused_lds() {
   return set_fused_lds_for<FusedAttnOp<4, ENC_DIM>>();
 }
 
+// (K parts of the partial launches: two on the MFMA engine, and on the GEMV engine next to the fused attention -
+// measured there 32.3 -> 31.8 us/step at T=100, but 33.5 -> 35.0 at T=250, where the energies / context launches
+// bring many workgroups of their own and the pieces stay whole.)
 // Early columns of the attention LSTM, [ctx(t-1); h_a(t-1)] -> g_a, for the step with chunk index i.
 Partial partial_attn(const ttsx_t2_decoder* d, int i) {
   GemmP g{};
   g.Bpad = d->Bpad, g.ctx = d->rc, g.step_in_chunk = i, g.parity = (d->parity0 + i) & 1;
   g.Wp = d->w_lstm1, g.nseg = 2, g.KG = (ENC_DIM + QUERY_DIM) / 16, g.kg0 = PRENET_DIM / 16, g.kg_stride = KG1;
   g.gates = d->g_a;
-  g.kparts = d->B > GEMV_MAX_B ? 2 : 1, g.gates_part_stride = QUERY_DIM * d->Bpad;
+  g.kparts = (d->B > GEMV_MAX_B || d->fused) ? 2 : 1, g.gates_part_stride = QUERY_DIM * d->Bpad;
   g.seg[0] = Seg{{d->ctx, nullptr}, 0, ENC_DIM / 16};
   g.seg[1] = Seg{{d->h_a[0], d->h_a[1]}, 1, QUERY_DIM / 16};
   return Partial{g, QUERY_DIM / 4};
@@ -1845,7 +1868,7 @@ Partial partial_dec(const ttsx_t2_decoder* d, int i) {
   g.Bpad = d->Bpad, g.ctx = d->rc, g.step_in_chunk = i, g.parity = (d->parity0 + i) & 1;
   g.Wp = d->w_lstm2, g.nseg = 2, g.KG = (QUERY_DIM + DEC_DIM) / 16, g.kg0 = ENC_DIM / 16, g.kg_stride = KG2;
   g.gates = d->g_d;
-  g.kparts = d->B > GEMV_MAX_B ? 2 : 1, g.gates_part_stride = DEC_DIM * d->Bpad;
+  g.kparts = (d->B > GEMV_MAX_B || d->fused) ? 2 : 1, g.gates_part_stride = DEC_DIM * d->Bpad;
   g.seg[0] = Seg{{d->h_a[0], d->h_a[1]}, 2, QUERY_DIM / 16};
   g.seg[1] = Seg{{d->h_d[0], d->h_d[1]}, 1, DEC_DIM / 16};
   return Partial{g, DEC_DIM / 4};
