@@ -374,7 +374,8 @@ int ttsx_spec_to_mag(const float* spec, const float* inv_basis, int B, int F, in
  *              draws it from the global NumPy RNG, utils.py:923)
  *   n_frames   [B] int32 valid frames per utterance or NULL (= F)
  *   iters      griffin_lim_iters (60)
- *   preemph    de-emphasis coefficient (0.98); 0 skips the filter
+ *   preemph    de-emphasis coefficient (0.98); 0 skips the filter; |preemph| <= 0.9899 (the filter runs as a blocked
+ *              scan that cuts its impulse response off after 2048 taps: |a|^2048 < 1e-9)
  *   wav        [B, hop*(F-1)] ; utterance b holds hop*(n_frames[b]-1) samples, rest zero   */
 int ttsx_griffin_lim(const float* mag, const float* init_phase, const int32_t* n_frames, int B, int F,
                      const ttsx_stft_params* sp, int iters, float preemph, float* wav, void* stream);

@@ -622,27 +622,64 @@ __global__ void pad_signal_kernel(float* __restrict__ ypad, const float* __restr
   ypad[(size_t)b * q.LP + g] = v;
 }
 
-// de-emphasis y[n] = x[n] + a*y[n-1] (lfilter([1],[1,-a])).  The impulse response a^k falls
-// below 1e-17 after 2048 taps (a = 0.98), so each thread rebuilds the recurrence for its own
-// 256-sample segment from a 2048-sample warm-up, in fp64 like the reference.
-constexpr int DE_SEG = 256, DE_WARM = 2048;
-__global__ void deemph_kernel(float* __restrict__ out, const float* __restrict__ x, size_t x_pitch,
-                              const int32_t* __restrict__ n_frames, int B, int F, int hop, float coef) {
-  const int b = blockIdx.y;
+// de-emphasis y[n] = x[n] + a*y[n-1] (lfilter([1],[1,-a])), in fp64 like the reference, as a blocked scan:
+//   1. every thread runs the recurrence over its own 64-sample segment from a zero state; the value it ends on is
+//      what the segment contributes to the state right behind it;
+//   2. the state a segment starts from is the sum of the 32 segments before it, each damped by a^64 per segment
+//      of distance (the impulse response a^k is below 1e-17 after 2048 taps for a = 0.98, so older input is
+//      beyond fp64 resolution);
+//   3. the recurrence again from that state, this time storing.
+// A workgroup (256 segments + 32 halo segments, whose end values the first 32 threads compute as well) stages
+// its 2048 + 16384 input samples in LDS with coalesced loads, one pad word per segment so that lanes at the same
+// offset of their segments hit different banks, overwrites them in place in step 3 and writes them back coalesced.
+// Serial chain per thread: 64 + 32 + 64 steps (a thread walking a 2048-sample warm-up before its segment, as an
+// earlier version did, pays 2304 dependent steps: 300 us for 64 x 220 000 samples against 20 us).
+constexpr int DE_SEG = 64, DE_HALO = 32, DE_SEGS_PER_WG = 256;
+constexpr int DE_STAGE = (DE_HALO + DE_SEGS_PER_WG) * DE_SEG;          // staged samples
+constexpr int DE_LDS_FLOATS = (DE_HALO + DE_SEGS_PER_WG) * (DE_SEG + 1);
+__device__ __forceinline__ int de_idx(int j) { return j + (j >> 6); }
+__device__ __forceinline__ double de_zero_state_end(const float* s_de, int j0, double a) {
+  double acc = 0.0;
+#pragma unroll 16
+  for (int k = 0; k < DE_SEG; ++k) acc = (double)s_de[de_idx(j0 + k)] + a * acc;
+  return acc;
+}
+__global__ __launch_bounds__(DE_SEGS_PER_WG) void deemph_kernel(float* __restrict__ out, const float* __restrict__ x,
+                                                               size_t x_pitch, const int32_t* __restrict__ n_frames,
+                                                               int B, int F, int hop, float coef) {
+  extern __shared__ float s_de[];
+  __shared__ double s_end[DE_HALO + DE_SEGS_PER_WG];
+  const int b = blockIdx.y, tid = threadIdx.x;
   const int Fb = n_frames ? n_frames[b] : F;
   const int Lmax = hop * (F - 1), L = hop * (Fb - 1);
-  const int seg = blockIdx.x * blockDim.x + threadIdx.x;
-  const int start = seg * DE_SEG;
-  if (start >= Lmax) return;
+  const int base = (blockIdx.x * DE_SEGS_PER_WG - DE_HALO) * DE_SEG;  // first sample of the staged window
   const float* xb = x + (size_t)b * x_pitch;
   float* ob = out + (size_t)b * Lmax;
-  double acc = 0.0;
+  for (int j = tid; j < DE_STAGE; j += DE_SEGS_PER_WG) {
+    const int n = base + j;
+    s_de[de_idx(j)] = (n >= 0 && n < Lmax) ? xb[n] : 0.f;   // (before the signal: zeros, i.e. a zero initial state)
+  }
+  __syncthreads();
   const double a = (double)coef;
-  for (int n = max(0, start - DE_WARM); n < start; ++n) acc = (double)xb[n] + a * acc;
-  const int end = min(start + DE_SEG, Lmax);
-  for (int n = start; n < end; ++n) {
-    acc = (double)xb[n] + a * acc;
-    ob[n] = n < L ? (float)acc : 0.f;
+  double r = a;  // a^64
+#pragma unroll
+  for (int i = 0; i < 6; ++i) r *= r;
+  const int j0 = (DE_HALO + tid) * DE_SEG;  // this thread's segment inside the window
+  s_end[DE_HALO + tid] = de_zero_state_end(s_de, j0, a);
+  if (tid < DE_HALO) s_end[tid] = de_zero_state_end(s_de, tid * DE_SEG, a);
+  __syncthreads();
+  double acc = 0.0;
+#pragma unroll 8
+  for (int m = DE_HALO; m >= 1; --m) acc = r * acc + s_end[DE_HALO + tid - m];
+#pragma unroll 16
+  for (int k = 0; k < DE_SEG; ++k) {
+    acc = (double)s_de[de_idx(j0 + k)] + a * acc;
+    s_de[de_idx(j0 + k)] = (float)acc;   // (only this thread reads or writes its segment from here on)
+  }
+  __syncthreads();
+  for (int j = DE_HALO * DE_SEG + tid; j < DE_STAGE; j += DE_SEGS_PER_WG) {
+    const int n = base + j;
+    if (n < Lmax) ob[n] = n < L ? s_de[de_idx(j)] : 0.f;
   }
 }
 
@@ -799,6 +836,9 @@ extern "C" int ttsx_griffin_lim(const float* mag, const float* init_phase, const
                                 const ttsx_stft_params* sp, int iters, float preemph, float* wav, void* stream) {
   TTSX_ARG(mag && init_phase && wav, "ttsx_griffin_lim: null argument");
   TTSX_ARG(iters >= 0, "ttsx_griffin_lim: iters=%d", iters);
+  // (the de-emphasis kernel cuts the filter's impulse response off after 2048 taps)
+  TTSX_ARG(pow(fabs((double)preemph), 2048.0) < 1e-9,
+           "ttsx_griffin_lim: preemphasis %g too close to 1 (|a|^2048 must be below 1e-9, i.e. |a| <= 0.9899)", preemph);
   int rc = check_stft_params(sp, B, F);
   if (rc) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -851,8 +891,12 @@ extern "C" int ttsx_griffin_lim(const float* mag, const float* init_phase, const
   if (!direct) {
     // the IIR reads the trimmed part of the last padded signal
     const int nseg = (int)((Lmax + DE_SEG - 1) / DE_SEG);
-    deemph_kernel<<<dim3(ceil_div(nseg, 64), B), 64, 0, st>>>(wav, ybuf[cur] + NFFT / 2, (size_t)q.LP, n_frames, B, F,
-                                                            sp->hop_length, preemph);
+    static const hipError_t de_attr = hipFuncSetAttribute(
+        reinterpret_cast<const void*>(deemph_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (int)(DE_LDS_FLOATS * sizeof(float)));
+    TTSX_HIP(de_attr);
+    deemph_kernel<<<dim3(ceil_div(nseg, DE_SEGS_PER_WG), B), DE_SEGS_PER_WG, DE_LDS_FLOATS * sizeof(float), st>>>(
+        wav, ybuf[cur] + NFFT / 2, (size_t)q.LP, n_frames, B, F, sp->hop_length, preemph);
     TTSX_LAUNCH_CHECK();
   }
   // the scratch is shared by every call in the process: finish before releasing the lock
