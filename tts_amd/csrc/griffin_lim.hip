@@ -704,18 +704,29 @@ __device__ inline float denorm_to_amp(float s, const ttsx_audio_params& a) {
       s = (s * -a.min_level_db / a.max_norm) + a.min_level_db;
     }
   }
-  return powf(10.0f, (s + a.ref_level_db) * 0.05f);
+  return exp2f((s + a.ref_level_db) * (0.05f * 3.32192809488736f));  // 10^(dB/20)
+}
+
+// x^p for x > 0 (the library powf spends most of its instructions on cases that cannot occur here; the common
+// exponent 1.5 is a multiply and a square root, anything else goes through exp2 / log2: relative error ~2e-6)
+__device__ __forceinline__ float pow_pos(float x, float p) {
+  if (p == 1.5f) return x * sqrtf(x);
+  if (p == 1.0f) return x;
+  return exp2f(p * log2f(x));
 }
 
 constexpr int MAG_ROWS = 8;
 __global__ __launch_bounds__(256) void spec_to_mag_kernel(MagP p) {
-  __shared__ float s_amp[MAG_ROWS][128];
+  // amplitudes of the workgroup's rows, channel-major: the MAG_ROWS values of a channel are two 16-byte
+  // broadcast reads in the contraction below instead of MAG_ROWS scalar ones
+  __shared__ __attribute__((aligned(16))) float s_amp[128][MAG_ROWS];
+  static_assert(MAG_ROWS == 8, "the contraction reads the rows of a channel as two float4");
   const long r0 = (long)blockIdx.x * MAG_ROWS;
   const int tid = threadIdx.x;
   if (p.inv_basis) {
     for (int i = tid; i < MAG_ROWS * p.C; i += 256) {
       const int rr = i / p.C, c = i % p.C;
-      s_amp[rr][c] = (r0 + rr < p.n_rows) ? denorm_to_amp(p.spec[(r0 + rr) * p.C + c], p.ap) : 0.f;
+      s_amp[c][rr] = (r0 + rr < p.n_rows) ? denorm_to_amp(p.spec[(r0 + rr) * p.C + c], p.ap) : 0.f;
     }
     __syncthreads();
     for (int k = tid; k < p.n_freq; k += 256) {
@@ -723,20 +734,32 @@ __global__ __launch_bounds__(256) void spec_to_mag_kernel(MagP p) {
 #pragma unroll
       for (int rr = 0; rr < MAG_ROWS; ++rr) acc[rr] = 0.f;
       const float* brow = p.inv_basis + (size_t)k * p.C;
-      for (int c = 0; c < p.C; ++c) {
-        const float w = brow[c];
-#pragma unroll
-        for (int rr = 0; rr < MAG_ROWS; ++rr) acc[rr] += w * s_amp[rr][c];
+      auto channel = [&](float w, int c) {
+        const float4 a0 = *reinterpret_cast<const float4*>(&s_amp[c][0]);
+        const float4 a1 = *reinterpret_cast<const float4*>(&s_amp[c][4]);
+        acc[0] += w * a0.x, acc[1] += w * a0.y, acc[2] += w * a0.z, acc[3] += w * a0.w;
+        acc[4] += w * a1.x, acc[5] += w * a1.y, acc[6] += w * a1.z, acc[7] += w * a1.w;
+      };
+      if ((p.C & 3) == 0) {
+        // (a row of the basis is C floats from a 16-byte boundary: four channels per load)
+        const float4* brow4 = reinterpret_cast<const float4*>(brow);
+#pragma unroll 4
+        for (int c4 = 0; c4 < p.C / 4; ++c4) {
+          const float4 w = brow4[c4];
+          channel(w.x, 4 * c4), channel(w.y, 4 * c4 + 1), channel(w.z, 4 * c4 + 2), channel(w.w, 4 * c4 + 3);
+        }
+      } else {
+        for (int c = 0; c < p.C; ++c) channel(brow[c], c);
       }
 #pragma unroll
       for (int rr = 0; rr < MAG_ROWS; ++rr)
-        if (r0 + rr < p.n_rows) p.mag[(r0 + rr) * p.n_freq + k] = powf(fmaxf(1e-10f, acc[rr]), p.ap.power);
+        if (r0 + rr < p.n_rows) p.mag[(r0 + rr) * p.n_freq + k] = pow_pos(fmaxf(1e-10f, acc[rr]), p.ap.power);
     }
   } else {
     for (int rr = 0; rr < MAG_ROWS; ++rr) {
       if (r0 + rr >= p.n_rows) break;
       for (int k = tid; k < p.n_freq; k += 256)
-        p.mag[(r0 + rr) * p.n_freq + k] = powf(denorm_to_amp(p.spec[(r0 + rr) * p.C + k], p.ap), p.ap.power);
+        p.mag[(r0 + rr) * p.n_freq + k] = pow_pos(denorm_to_amp(p.spec[(r0 + rr) * p.C + k], p.ap), p.ap.power);
     }
   }
 }
