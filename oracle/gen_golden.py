@@ -3,6 +3,7 @@
 Usage (from the repo root, in the container that mounts /root/reference):
 
     python oracle/gen_golden.py t2      # Tacotron2 model fixtures
+    python oracle/gen_golden.py t2long  # Tacotron2 at 800 / 2000 decoder steps (long-horizon drift)
     python oracle/gen_golden.py t2v     # Tacotron2 optional variants (windowing, forward / Graves
                                         # attention, speaker embedding, inference_truncated)
     python oracle/gen_golden.py t2audio # AudioProcessor pieces that run without librosa
@@ -103,6 +104,71 @@ def gen_t2():
         print(name, "steps", align.shape[1], "frames", dec.shape[1],
               "stop last %.4f max-before %.4f" % (float(stop[0, -1, 0]),
                                                   float(stop[0, :-1, 0].max()) if stop.shape[1] > 1 else 0))
+
+
+# ------------------------------------------------------------------ Tacotron2, long horizons
+# The two configurations that run for hundreds of steps (64 x 128 ids for 800 steps; 1000 ids for
+# 2000 steps) through the reference's own Decoder.inference (Tacotron2/TTS/models.py:643-673), with
+# the weights the benchmark uses (seed 0, default gains) except a stop bias of -30 so that the
+# reference's stop rule never fires: the stop token does not feed back, so mel frames and
+# alignments are those of the benchmark's fixed-step run.  Kept: every mel frame; at the checkpoint
+# steps the recurrent state (so that a test can restart there and compare the following steps
+# without hundreds of steps of accumulated rounding drift), the alignment rows of the step and the
+# next few, and a 16-frame postnet window.
+LONG_NEXT = 8   # steps after a checkpoint whose alignment rows are kept
+T2_LONG_CASES = [
+    # name, T_in, ids (seed, rows, row index), steps, checkpoint steps (1-based)
+    ("t2long_sigmoid_bn_r1_T128_fixed800", 128, (4242, 8, 3), 800, (1, 50, 100, 200, 400, 600, 800)),
+    ("t2long_sigmoid_bn_r1_T1000_fixed2000", 1000, (77, 1, 0), 2000, (1, 50, 100, 200, 400, 800, 1200, 1600, 2000)),
+]
+
+
+def gen_t2long():
+    sys.path.insert(0, os.path.join(REF, "Tacotron2"))
+    from TTS.models import Tacotron2  # the reference implementation
+    gains = {"stop_bias": -30.0}
+    sd = synthetic.t2_state_dict(seed=0, gains=gains)
+    model = Tacotron2(num_chars=129, num_speakers=0, r=7, attn_norm="sigmoid", prenet_type="bn",
+                      prenet_dropout=False, separate_stopnet=True)
+    model.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
+    model.eval()
+    model.decoder.set_r(1)
+    orig_decode = model.decoder.decode
+    for name, T, (ids_seed, rows, row), steps, marks in T2_LONG_CASES:
+        model.decoder.max_decoder_steps = steps
+        ids = synthetic.t2_text_ids(ids_seed, rows, T)[row:row + 1]
+        marks = np.array(marks)
+        rec, count = {}, [0]
+
+        # the recurrent state after each checkpoint step (= what the step after it starts from)
+        def decode(memory, _rec=rec, _count=count, _marks=set(int(m) for m in marks)):
+            out = orig_decode(memory)
+            _count[0] += 1
+            if _count[0] in _marks:
+                d = model.decoder
+                st = dict(h_a=d.query, c_a=d.attention_rnn_cell_state, h_d=d.decoder_hidden, c_d=d.decoder_cell,
+                          ctx=d.context, a_prev=d.attention.attention_weights,
+                          a_cum=d.attention.attention_weights_cum)
+                _rec[_count[0]] = {k: v.detach().clone().numpy()[0] for k, v in st.items()}
+            return out
+        model.decoder.decode = decode
+        with torch.no_grad():
+            dec, post, align, stop = model.inference(torch.as_tensor(ids))
+        assert align.shape[1] == steps and sorted(rec) == sorted(int(m) for m in marks), align.shape
+        win_lo = np.clip(marks - 1 - 8, 0, steps - 16)
+        post_win = np.stack([post[0, lo:lo + 16].numpy() for lo in win_lo])
+        # alignment rows of the checkpoint step and of the NEXT steps (rows m-1 .. m-1+NEXT, clipped)
+        nxt = np.stack([align[0, np.clip(np.arange(m - 1, m + LONG_NEXT), 0, steps - 1)].numpy() for m in marks])
+        state = {"state_" + k: np.stack([rec[int(m)][k] for m in marks]) for k in rec[int(marks[0])]}
+        meta = dict(attn_norm="sigmoid", prenet_type="bn", r=1, r_init=7, weight_seed=0, gains=gains,
+                    ids_seed=ids_seed, ids_rows=rows, ids_row=row, T_in=T, max_decoder_steps=steps, next=LONG_NEXT)
+        np.savez_compressed(os.path.join(GOLD, name + ".npz"), meta=json.dumps(meta), ids=ids,
+                            decoder_output=dec[0].numpy(), marks=marks, alignments_from_marks=nxt,
+                            postnet_window_start=win_lo, postnet_windows=post_win,
+                            stop_max=np.array(float(stop.max())), **state)
+        al = align[0].numpy()
+        print(name, "steps", steps, "mel std %.3f |max| %.2f" % (float(dec.std()), float(dec.abs().max())),
+              "align max", float(al.max()), "stop max", float(stop.max()))
 
 
 # ------------------------------------------------------------------ Tacotron2 optional variants
@@ -292,4 +358,4 @@ def gen_text():
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    {"t2": gen_t2, "t2v": gen_t2v, "t2audio": gen_t2audio, "t1": gen_t1, "text": gen_text}[sys.argv[1]]()
+    {"t2": gen_t2, "t2long": gen_t2long, "t2v": gen_t2v, "t2audio": gen_t2audio, "t1": gen_t1, "text": gen_text}[sys.argv[1]]()
