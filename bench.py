@@ -2,23 +2,40 @@
 """Benchmark of the synthesis hot path: mel frames/s of Tacotron2 + Griffin-Lim.
 
 One "step" = one pass of the whole path over one batch of synthetic sentences that is
-already resident in HBM: encoder -> greedy decoder (fixed number of decoder steps) ->
-postnet -> mel-to-linear -> 60-iteration Griffin-Lim -> de-emphasis.  Default workload:
-64 sentences x 128 phoneme ids, 800 decoder steps, r = 1 (51 200 mel frames per step), the
-"Tacotron2 batch=64 synthetic sentences, fixed 800 decoder steps" configuration.  With
---gpus N every rank runs that workload on its own GPU (independent utterances, no
-data-path collective); value = frames of all ranks / max-over-ranks time.
+already resident in HBM: encoder -> greedy decoder -> postnet -> mel-to-linear -> 60-iteration
+Griffin-Lim -> de-emphasis.
+
+Workloads (--workload):
+  batch   (default) 64 sentences x 128 phoneme ids, 800 fixed decoder steps, r = 1 (51 200 mel frames
+          per step): the "Tacotron2 batch=64 synthetic sentences, fixed 800 decoder steps" configuration.
+          With --gpus N every rank runs it on its own GPU with its own sentences; value = frames of all
+          ranks / max-over-ranks time ("weak" scaling).
+  corpus  the 4096-utterance ragged corpus (text lengths uniform in 20..200, seed 1234; min(3000, 6 x length)
+          decoder steps per utterance), length-sorted into batches of 64 that are dealt to the ranks
+          longest-processing-time first; a step = one pass over the rank's share; value = frames of the
+          whole corpus / max-over-ranks time ("strong" scaling), with per-rank frames and busy time.
+The default line also carries a `corpus` block: the whole corpus over the N ranks when N > 1, one eighth of
+it (what one of eight GPUs would get) when N = 1.
+
+--gpus N without a torch.distributed environment starts the N ranks itself (fresh child processes, before
+anything in this process touches the GPU); under `torch.distributed.run` the ranks are already there and
+--gpus must equal WORLD_SIZE.  Independent utterances, weights replicated, no data-path collective:
+torch.distributed (RCCL) carries the timing barrier and a few reporting scalars only.
 
 The JSON line also carries
   roofline      the decoder step (the dominant stage) against the chip's fp32-MFMA / HBM peak,
                 from HIP-event timing on the launch stream inside this run;
+  roofline_gl   the Griffin-Lim stage against the HBM and vector-ALU peaks;
   cpu_baseline  the CPU oracle (a restatement of the reference's PyTorch/NumPy path) timed on
                 this box's host cores on a bounded sample of the same workload (rank 0, N=1);
-  batch1        batch-1 latency and real-time factor of the same path.
+  batch1        batch-1 latency and real-time factor of the same path, fixed 800 steps;
+  batch1_stop_driven  the same at batch 1 with the stop token ending the decode.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,8 +46,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak
-MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32 matrix peak
+MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32 matrix peak (= fp32 vector peak)
 DEC_WEIGHT_BYTES = 18928802 * 4  # decoder parameters read once per step (inputs_layer excluded)
+GL_BYTES_PER_FRAME = 61 * 1025 * 4 + 121 * 275 * 4   # 60 iterations: magnitudes read 61 x, signal read + written
+GL_FLOPS_PER_FRAME = 121 * 2.5 * 2048 * 11           # 121 real FFTs of 2048 points
 
 
 def dec_step_bytes(B, T):
@@ -41,11 +60,11 @@ def dec_step_flops(B, T):
     return B * (37.81e6 + 13440.0 * T)
 
 
-def build_model(device, r):
+def build_model(device, r, gains=None):
     from tts_amd import synthetic
     from tts_amd.audio import AudioProcessor
     from tts_amd.tacotron2 import Tacotron2
-    sd = synthetic.t2_state_dict(seed=0)
+    sd = synthetic.t2_state_dict(seed=0, gains=gains)
     model = Tacotron2(num_chars=129, num_speakers=0, r=7, attn_norm="sigmoid", prenet_type="bn",
                       prenet_dropout=False, separate_stopnet=True)
     model.load_state_dict(sd)
@@ -173,23 +192,173 @@ def tacotron_v1_batch1(dev, T_in=100, steps=200):
             "stage_ms": {"encoder": st[0], "decoder": st[1], "postnet": st[2], "griffin_lim": st[3]}}
 
 
+def batch1_stop_driven(dev, ap):
+    """Batch 1 as a server request runs it: the decoder stops when its stop token exceeds 0.7 (a late-stop
+    synthetic checkpoint: the stop step depends on the text and lies near step 309), then postnet and
+    Griffin-Lim over the frames it produced."""
+    from tts_amd import synthetic
+    model, _, _ = build_model(dev.index, 1, gains=synthetic.T2_LATE_STOP_GAINS)
+    model.decoder.max_decoder_steps = 3000
+    ids = torch.as_tensor(synthetic.t2_text_ids(99, 1, 100)).to(dev)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+
+    def run(record=False):
+        enc = model.encode(ids)
+        if record:
+            ev[0].record()
+        mel, align, stop, n_steps, steps = model.decode(enc, None)
+        if record:
+            ev[1].record()
+        post = model.postnet(mel)
+        ph = torch.rand(1, post.shape[1], 1025, device=dev)
+        wav = ap.griffin_lim_batch(ap.spec_to_mag(post), ph)
+        if record:
+            ev[2].record()
+        return int(n_steps[0]), model.last_steps_launched()
+
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        run()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            n, launched = run()
+        torch.cuda.synchronize()
+        lat = (time.perf_counter() - t0) / 3
+        run(record=True)
+        torch.cuda.synchronize()
+    dec_ms, rest_ms = ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2])
+    audio_s = n * 275 / 22050.0
+    return {"workload": "B=1, T_in=100, stop-driven (threshold 0.7, max_decoder_steps 3000), r=1",
+            "n_steps": n, "steps_launched": launched, "latency_s": lat, "audio_s": audio_s,
+            "real_time_factor": lat / audio_s, "frames_per_s": n / lat,
+            "decoder_ms": dec_ms, "decoder_us_per_needed_step": dec_ms * 1e3 / n, "postnet_vocoder_ms": rest_ms}
+
+
+# ---------------------------------------------------------------------------------------------- ranks
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(a, argv):
+    """Start a.gpus fresh child processes, one rank each (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set), wait
+    for them and return the worst exit status.  Runs before this process has made any GPU call; rank 0's JSON
+    line goes to this process's stdout."""
+    if not a.dry_run:
+        n_dev = torch.cuda.device_count()   # (counting devices does not initialise the GPU)
+        if a.gpus > n_dev:
+            sys.stderr.write("bench.py: --gpus %d asked for but this node shows %d GPU(s)\n" % (a.gpus, n_dev))
+            return 2
+    port = _free_port()
+    procs = []
+    for rank in range(a.gpus):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    worst = 0
+    for p in procs:
+        rc = p.wait()
+        if rc != 0:
+            worst = rc if worst == 0 else worst
+    return worst
+
+
+def corpus_plan_summary(a, world):
+    from tts_amd import corpus
+    lengths = corpus.corpus_lengths(a.corpus_utts, seed=1234)
+    batches = corpus.plan_batches(lengths, a.batch)
+    return lengths, batches, corpus.deal(batches, lengths, world, "lpt")
+
+
+def dry_run(a, rank, world):
+    """The launcher and the corpus plan without a GPU: every rank derives its shard, the reporting exchange
+    runs over gloo, rank 0 prints what each rank would synthesise."""
+    from tts_amd import corpus
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    lengths, batches, dealt = corpus_plan_summary(a, world)
+    mine = [batches[i] for i in dealt[rank]]
+    utts = sorted(int(i) for b in mine for i in b)
+    frames = float(sum(int(np.minimum(3000, 6 * lengths[b]).sum()) * a.r for b in mine))
+    stats = corpus.gather_rank_stats([rank, len(mine), len(utts), frames, utts[0], utts[-1],
+                                      float(np.sum(utts) % 1000003)], dist)
+    total = corpus.reduce_scalar(frames, "sum", dist)
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "workload": a.workload, "corpus_utterances": a.corpus_utts,
+                          "total_frames": total,
+                          "ranks": [dict(rank=int(s[0]), batches=int(s[1]), utterances=int(s[2]), frames=s[3],
+                                         first_utt=int(s[4]), last_utt=int(s[5]), utt_checksum=int(s[6]))
+                                    for s in stats]}))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+def run_corpus(a, model, ap, rank, world, dist, dev, n_utts, shard_of=None):
+    """Time `a.steps` passes over this rank's share of the corpus.  shard_of = (world', rank'): take the share
+    rank' of world' ranks would get (used at N=1 to run what one of eight GPUs would)."""
+    from tts_amd import corpus
+    lengths = corpus.corpus_lengths(n_utts, seed=1234)
+    texts = corpus.corpus_texts(lengths, seed=1234)
+    w, r_ = (world, rank) if shard_of is None else shard_of
+    staged = corpus.StagedCorpus(model, ap, lengths, texts, batch=a.batch, world=w, rank=r_, policy="lpt",
+                                 steps_per_id=6, max_steps=3000, device=dev)
+    dt, busy = corpus.timed_steps(staged.run, a.steps, a.warmup, dist, dev, own=True)
+    stats = corpus.gather_rank_stats([staged.frames, staged.frames_padded, busy / a.steps, staged.n_utts,
+                                      len(staged.items)], dist, dev if dist is not None else None)
+    frames = float(stats[:, 0].sum())
+    ms = dt / a.steps * 1e3
+    return {"workload": "Tacotron2, %d-utterance synthetic corpus (T_in uniform 20..200, seed 1234), min(3000, 6 x T_in) "
+                        "decoder steps, r=%d, length-sorted batches of %d dealt longest-processing-time first%s, "
+                        "postnet + 60-iter Griffin-Lim" % (n_utts, staged.r, a.batch,
+                                                            "" if shard_of is None else
+                                                            "; share %d of %d" % (shard_of[1], shard_of[0])),
+            "frames": frames, "ms_per_pass": ms, "frames_per_s": frames / (ms * 1e-3),
+            "per_rank": [dict(frames=float(s[0]), frames_computed=float(s[1]), busy_ms=float(s[2] * 1e3),
+                              utterances=int(s[3]), batches=int(s[4])) for s in stats],
+            "imbalance": float(stats[:, 2].max() / max(stats[:, 2].mean(), 1e-12))}
+
+
 def main():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=3)
     p.add_argument("--warmup", type=int, default=1)
+    p.add_argument("--workload", choices=("batch", "corpus"), default="batch")
     p.add_argument("--batch", type=int, default=64)
     p.add_argument("--t-in", type=int, default=128)
     p.add_argument("--dec-steps", type=int, default=800)
     p.add_argument("--r", type=int, default=1)
+    p.add_argument("--corpus-utts", type=int, default=4096)
     p.add_argument("--cpu-sample-steps", type=int, default=1600)  # ~11 s of host work
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-batch1", action="store_true")
+    p.add_argument("--no-corpus", action="store_true")
+    p.add_argument("--dry-run", action="store_true", help="launcher + corpus plan only (no GPU; gloo)")
     a = p.parse_args()
+    if a.gpus < 1:
+        p.error("--gpus must be >= 1")
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(a, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        sys.stderr.write("bench.py: --gpus %d does not match WORLD_SIZE=%d\n" % (a.gpus, world))
+        sys.exit(2)
+    if a.dry_run:
+        sys.exit(dry_run(a, rank, world))
+    if local_rank >= torch.cuda.device_count():
+        sys.stderr.write("bench.py: rank %d has no GPU (%d visible)\n" % (local_rank, torch.cuda.device_count()))
+        sys.exit(2)
+
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -198,21 +367,41 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    from tts_amd import synthetic
+    from tts_amd import corpus, synthetic
     model, ap, sd = build_model(local_rank, a.r)
     B, T, S, r = a.batch, a.t_in, a.dec_steps, a.r
-    # every rank gets its own sentences (the 4096-utterance corpus dealt out in batches)
-    ids = torch.as_tensor(synthetic.t2_text_ids(1234 + rank, B, T)).to(dev)
     F_total = S * r
+    out = {"metric": "mel frames/sec, Tacotron2+Griffin-Lim", "unit": "mel frames/s", "n_gpus": world,
+           "steps": a.steps, "warmup": a.warmup, "higher_is_better": True, "vs_baseline": None, "dtype": "f32",
+           "data": "synthetic (seeded weights in the repo config's architecture, random phoneme ids, random GL phase)"}
+
+    if a.workload == "corpus":
+        c = run_corpus(a, model, ap, rank, world, dist, dev, a.corpus_utts)
+        out.update(value=c["frames_per_s"], ms_per_step=c["ms_per_pass"], scaling="strong",
+                   config={"workload": c["workload"], "global_batch": a.corpus_utts,
+                           "parallelism": "dp%d (independent utterances, no collective)" % world},
+                   corpus=c)
+    # the fixed batch: headline of the default workload, and the source of the stage split / roofline
+    # every rank gets its own sentences
+    ids = torch.as_tensor(synthetic.t2_text_ids(1234 + rank, B, T)).to(dev)
     phase = torch.rand(B, F_total, 1025, device=dev, generator=torch.Generator(device=dev).manual_seed(rank))
     wl = Workload(model, ap, ids, S, phase)
-
-    from tts_amd import corpus
-    # warm-up, then exactly `steps` timed passes between synchronise + barrier fences; max over ranks
-    dt = corpus.timed_steps(wl.run, a.steps, a.warmup, dist, dev)
-    ms_per_step = dt / a.steps * 1e3
-    frames_per_step = B * F_total * world
-    value = frames_per_step / (ms_per_step * 1e-3)
+    if a.workload == "batch":
+        # warm-up, then exactly `steps` timed passes between synchronise + barrier fences; max over ranks
+        dt = corpus.timed_steps(wl.run, a.steps, a.warmup, dist, dev)
+        ms_per_step = dt / a.steps * 1e3
+        out.update(value=B * F_total * world / (ms_per_step * 1e-3), ms_per_step=ms_per_step, scaling="weak",
+                   config={"workload": "Tacotron2 batch=%d synthetic sentences (T_in=%d), fixed %d decoder steps, r=%d, "
+                                       "postnet + 60-iter Griffin-Lim, per GPU" % (B, T, S, r),
+                           "global_batch": B * world,
+                           "parallelism": "dp%d (independent utterances, no collective)" % world},
+                   real_time_factor_batch=ms_per_step * 1e-3 / (B * F_total * 275 / 22050.0))
+        if not a.no_corpus:
+            # the ragged corpus next to it: all of it over the N ranks, or one eighth of it on a single GPU
+            out["corpus"] = run_corpus(a, model, ap, rank, world, dist, dev, a.corpus_utts,
+                                       shard_of=(8, 0) if world == 1 else None)
+    else:
+        wl.run()
 
     # stage split and decoder-step roofline from HIP events on the launch stream (untimed extra passes)
     for _ in range(2):
@@ -230,30 +419,30 @@ def main():
     # HBM bytes per step from the PMC passes kept under profiles/ (a separate rocprofv3 run on the same
     # workload; counters cannot be read from inside this process)
     roof["traffic"] = None
-    pmc_path = os.path.join(ROOT, "profiles", "r1_decoder_pmc.json")
-    if os.path.exists(pmc_path):
-        pmc = json.load(open(pmc_path))
-        if (pmc.get("B"), pmc.get("T")) == (B, T):
-            roof["traffic"] = pmc["hbm_bytes_per_step"]
-            roof["traffic_source"] = "profiles/r1_decoder_pmc.csv"
-    roof["kernel"] = ("t2 decoder step (5 launches: prenet-2, attention LSTM + query shares, fused attention, "
+    for name in ("r2_decoder_pmc.json", "r1_decoder_pmc.json"):
+        pmc_path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(pmc_path):
+            pmc = json.load(open(pmc_path))
+            if (pmc.get("B"), pmc.get("T")) == (B, T):
+                roof["traffic"] = pmc["hbm_bytes_per_step"]
+                roof["traffic_source"] = "profiles/" + name.replace(".json", ".csv")
+                break
+    roof["kernel"] = ("t2 decoder step (launch group: prenet-2, attention LSTM + query shares, fused attention, "
                       "decoder LSTM, projection; the early LSTM columns ride along as partial pieces)")
     roof["us_per_launch_group"] = dec_us
     roof["algorithmic_bytes"] = nbytes
     roof["algorithmic_flops"] = flops
     roof["hbm_equiv_gbs"] = nbytes / (dec_us * 1e-6) / 1e9
-
-    out = {
-        "metric": "mel frames/sec, Tacotron2+Griffin-Lim", "value": value, "unit": "mel frames/s",
-        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-        "data": "synthetic (seeded weights in the repo config's architecture, random phoneme ids, random GL phase)",
-        "config": {"workload": "Tacotron2 batch=%d synthetic sentences (T_in=%d), fixed %d decoder steps, r=%d, "
-                               "postnet + 60-iter Griffin-Lim, per GPU" % (B, T, S, r),
-                   "global_batch": B * world, "parallelism": "dp%d (independent utterances, no collective)" % world},
-        "real_time_factor_batch": ms_per_step * 1e-3 / (B * F_total * 275 / 22050.0),
-        "stage_ms": st, "roofline": roof,
-    }
+    gl_s = st["griffin_lim"] * 1e-3
+    n_fr = B * F_total
+    out.update(stage_ms=st, roofline=roof,
+               roofline_gl={"kernel": "gl_fused_kernel (one launch per Griffin-Lim iteration) + de-emphasis",
+                            "frames": n_fr, "ms": st["griffin_lim"],
+                            "hbm": {"achieved": n_fr * GL_BYTES_PER_FRAME / gl_s / 1e9, "peak": HBM_PEAK_GBS,
+                                    "unit": "GB/s", "frac": n_fr * GL_BYTES_PER_FRAME / gl_s / 1e9 / HBM_PEAK_GBS},
+                            "valu": {"achieved": n_fr * GL_FLOPS_PER_FRAME / gl_s / 1e12,
+                                     "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                     "frac": n_fr * GL_FLOPS_PER_FRAME / gl_s / 1e12 / MFMA_F32_PEAK_TFLOPS}})
 
     if rank == 0 and world == 1 and not a.no_batch1:
         ids1 = torch.as_tensor(synthetic.t2_text_ids(99, 1, 100)).to(dev)
@@ -275,6 +464,7 @@ def main():
                          "decoder_hbm_gbs": dec_step_bytes(1, 100) / (d_us * 1e-6) / 1e9,
                          "decoder_hbm_frac": dec_step_bytes(1, 100) / (d_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                          "workload": "B=1, T_in=100, %d decoder steps, r=%d" % (S, r)}
+        out["batch1_stop_driven"] = batch1_stop_driven(dev, ap)
         import contextlib
         import io
         with contextlib.redirect_stdout(io.StringIO()):   # the model reports 'max_decoder_steps' like the reference

@@ -140,6 +140,12 @@ int ttsx_t2_decoder_run(ttsx_t2_decoder* dec, const float* enc, const int32_t* e
                         int r, int max_steps, float stop_threshold, int fixed_steps, float* mel,
                         float* align, float* stop, int32_t* n_steps, int* steps_run_host, void* stream);
 
+/* Decoder steps the last ttsx_t2_decoder_run enqueued.  A free run notices the stop token of its last
+ * utterance a few steps late (the loop of models.py:651-668 asks the device after every step; here the
+ * host looks at a flag the device raises); the steps enqueued past it do no work that is kept.  No reference
+ * counterpart: a diagnostic for latency accounting. */
+int ttsx_t2_decoder_steps_launched(const ttsx_t2_decoder* dec);
+
 /* Step-level access for teacher-forced parity checks (Decoder.decode,
  * models.py:578-617).  begin() zero-initialises the recurrent state
  * (models.py:536-552, 240-249) and computes processed_inputs; load_state()

@@ -68,6 +68,7 @@ def test_entry_points_reject_bad_arguments_before_any_device_call():
         "ttsx_t2_decoder_set_initial": lambda: lib.ttsx_t2_decoder_set_initial(None, 0, None, 1, None),
         "ttsx_t2_decoder_run": lambda: lib.ttsx_t2_decoder_run(None, one, None, 1, 8, 1, 10, 0.5, 0, one, one, one,
                                                                one, byref(n), None),
+        "ttsx_t2_decoder_steps_launched": lambda: lib.ttsx_t2_decoder_steps_launched(None),
         "ttsx_t2_decoder_begin": lambda: lib.ttsx_t2_decoder_begin(None, one, None, 1, 8, None),
         "ttsx_t2_decoder_load_state": lambda: lib.ttsx_t2_decoder_load_state(None, *([None] * 7), None),
         "ttsx_t2_decoder_step": lambda: lib.ttsx_t2_decoder_step(None, one, 1, one, one, one, None),

@@ -89,3 +89,59 @@ def test_two_gloo_ranks_share_a_plan_and_agree_on_max_time_and_total(tmp_path):
     assert r0[2] + r1[2] == r0[1]
     ids0, ids1 = set(r0[3:].astype(int)), set(r1[3:].astype(int))
     assert not (ids0 & ids1) and ids0 | ids1 == set(range(300))      # disjoint, complete
+
+
+def _bench(*args):
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(args), capture_output=True, text=True,
+                          env=env, timeout=300), json
+
+
+def test_bench_launcher_starts_n_ranks_with_distinct_shards():
+    """`bench.py --gpus 2 --dry-run` (no GPU, gloo): the launcher starts two ranks, each derives its share of
+    the 4096-utterance corpus, and the shares are disjoint and complete."""
+    run, json = _bench("--gpus", "2", "--dry-run", "--workload", "corpus")
+    assert run.returncode == 0, run.stderr
+    line = json.loads(run.stdout.strip().splitlines()[-1])
+    assert line["dry_run"] and line["n_gpus"] == 2 and len(line["ranks"]) == 2
+    r0, r1 = line["ranks"]
+    assert (r0["rank"], r1["rank"]) == (0, 1)
+    assert r0["utterances"] + r1["utterances"] == 4096 and r0["batches"] + r1["batches"] == 64
+    assert r0["utt_checksum"] != r1["utt_checksum"]
+    lengths = corpus.corpus_lengths(4096, seed=1234)
+    assert line["total_frames"] == float(np.minimum(3000, 6 * lengths).sum())
+    assert abs(r0["frames"] - r1["frames"]) < 0.02 * line["total_frames"]        # LPT balance
+    # the same plan, derived here
+    batches = corpus.plan_batches(lengths, 64)
+    dealt = corpus.deal(batches, lengths, 2, "lpt")
+    for r, info in enumerate((r0, r1)):
+        utts = sorted(int(i) for b in dealt[r] for i in batches[b])
+        assert (utts[0], utts[-1], len(utts)) == (info["first_utt"], info["last_utt"], info["utterances"])
+
+
+def test_bench_refuses_more_ranks_than_gpus_and_a_mismatched_world():
+    """Asking for more GPUs than the node shows fails loudly instead of running fewer ranks; so does a
+    --gpus that contradicts WORLD_SIZE."""
+    import torch
+    run, _ = _bench("--gpus", str(torch.cuda.device_count() + 1))
+    assert run.returncode != 0 and "GPU" in run.stderr
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--dry-run"], capture_output=True,
+                         text=True, env=env, timeout=120)
+    assert run.returncode != 0 and "WORLD_SIZE" in run.stderr
+
+
+def test_corpus_texts_do_not_depend_on_the_cut():
+    lengths = corpus.corpus_lengths(50, seed=3)
+    texts = corpus.corpus_texts(lengths, seed=3)
+    assert [len(t) for t in texts] == lengths.tolist()
+    assert all(t.min() >= 3 and t.max() < 129 for t in texts)
+    again = corpus.corpus_texts(lengths, seed=3)
+    assert all((a == b).all() for a, b in zip(texts, again))

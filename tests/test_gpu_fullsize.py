@@ -200,3 +200,36 @@ def test_row3_of_the_full_batch_follows_the_reference(decoded):
     al = out["alignments"][3].cpu().numpy()[early - 1]
     ref_al = g["alignments_from_marks"][:len(early), 0]
     assert np.abs(al - ref_al).max() < 1e-3 and _argmax_agrees(al, ref_al)
+
+
+def test_staged_corpus_two_ranks_equal_one_rank_and_batch1(model):
+    """192 utterances of the ragged corpus (three batches of 64) as one rank and as two ranks run one after
+    the other on this GPU: every utterance once, bit-identical mel and waveform wherever it was placed; the
+    frame counts are the per-utterance min(3000, 6 x length); one utterance close to its own batch-1 run."""
+    from tts_amd import corpus
+    m, ap, sd = model
+    n = 192
+    lengths = corpus.corpus_lengths(n, seed=1234)
+    texts = corpus.corpus_texts(lengths, seed=1234)
+    kw = dict(batch=64, policy="lpt", steps_per_id=6, max_steps=3000)
+    one = corpus.StagedCorpus(m, ap, lengths, texts, world=1, rank=0, **kw)
+    assert one.n_utts == n and one.frames == int((6 * lengths).sum()) and one.frames_padded >= one.frames
+    ref = one.run(keep=True)
+    assert sorted(ref) == list(range(n))
+    seen = {}
+    for rank in range(2):
+        part = corpus.StagedCorpus(m, ap, lengths, texts, world=2, rank=rank, **kw)
+        got = part.run(keep=True)
+        assert not (set(got) & set(seen))
+        seen.update(got)
+    assert sorted(seen) == list(range(n))
+    for i in range(n):
+        assert ref[i][0].shape == (6 * lengths[i], 80) and ref[i][1].shape == (275 * (6 * lengths[i] - 1),)
+        assert np.array_equal(ref[i][0], seen[i][0]) and np.array_equal(ref[i][1], seen[i][1]), i
+        assert np.isfinite(ref[i][1]).all() and np.abs(ref[i][1]).max() > 0
+    # the shortest utterance of the longest batch alone, unpadded (GEMV engine instead of MFMA tiles)
+    i = int(corpus.plan_batches(lengths, 64)[0][-1])
+    steps = 6 * int(lengths[i])
+    solo = m.inference_batch(torch.as_tensor(texts[i][None]), fixed_steps=steps)
+    err = np.abs(solo["postnet_output"][0].cpu().numpy() - ref[i][0]).max(-1)
+    assert err[:LONG_FREE].max() < 1e-3 and err.max() < 0.2

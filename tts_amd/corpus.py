@@ -22,6 +22,14 @@ def corpus_lengths(n=4096, seed=1234, lo=20, hi=200):
     return synthetic.integers(seed, "corpus.lengths", (n,), lo, hi + 1).astype(np.int64)
 
 
+def corpus_texts(lengths, seed=1234, num_chars=129):
+    """Phoneme ids of the synthetic corpus: utterance i is the first lengths[i] entries of row i of one
+    seeded table, so it does not depend on how the corpus is cut up."""
+    lengths = np.asarray(lengths)
+    table = synthetic.integers(seed, "corpus.ids", (len(lengths), int(lengths.max())), 3, num_chars)
+    return [table[i, :int(n)] for i, n in enumerate(lengths)]
+
+
 def plan_batches(lengths, batch=64):
     """Sort by length (longest first, index as tie-break so the plan is unique) and cut into
     batches: rows of one batch have similar decode lengths, so little of a batch idles."""
@@ -69,18 +77,21 @@ def pad_batch(texts, idx):
     return ids, lens
 
 
-def timed_steps(run, steps, warmup, dist=None, device=None):
+def timed_steps(run, steps, warmup, dist=None, device=None, own=False):
     """`warmup` untimed calls of run(), then exactly `steps` timed ones, bracketed by a device
-    synchronise + barrier on both sides.  Returns the elapsed seconds, MAX over ranks."""
+    synchronise + barrier on both sides.  Returns the elapsed seconds, MAX over ranks; with `own`
+    a pair (that, this rank's own busy seconds up to its device synchronise, before the barrier)."""
     cuda = device is not None and torch.device(device).type == "cuda"
 
-    def fence():
+    def sync():
         if cuda:
             torch.cuda.synchronize(device)
+
+    def fence():
+        sync()
         if dist is not None:
             dist.barrier()
-            if cuda:
-                torch.cuda.synchronize(device)
+            sync()
 
     for _ in range(warmup):
         run()
@@ -88,9 +99,12 @@ def timed_steps(run, steps, warmup, dist=None, device=None):
     t0 = time.perf_counter()
     for _ in range(steps):
         run()
+    sync()
+    busy = time.perf_counter() - t0
     fence()
     dt = time.perf_counter() - t0
-    return reduce_scalar(dt, "max", dist, device)
+    dt = reduce_scalar(dt, "max", dist, device)
+    return (dt, busy) if own else dt
 
 
 def reduce_scalar(x, op, dist=None, device=None):
@@ -130,3 +144,70 @@ def synthesize_corpus(model, ap, texts, batch=64, world=1, rank=0, policy="lpt",
             F = int(nf[row])
             out[int(i)] = dict(wav=wav[row, :ap.hop_length * max(F - 1, 0)], mel=post[row, :F], n_frames=F)
     return out
+
+
+class StagedCorpus:
+    """This rank's share of a corpus, resident in device memory before any timing starts: padded ids,
+    text lengths, decoder steps and Griffin-Lim initial phases of every batch.
+
+    Decoder steps are fixed by the text: utterance i gets min(max_steps, steps_per_id * len_i) steps (r frames
+    each); a batch runs to its longest member and the shorter ones are cut to their own count afterwards
+    (postnet and vocoder take per-utterance frame counts), so an utterance's frames are those of its
+    batch-1 run.  The plan (which utterances share a batch) does not depend on world or rank; only the
+    dealing of batches to ranks does.  A batch's initial phases come from a device generator seeded with the
+    batch's index in the plan."""
+
+    def __init__(self, model, ap, lengths, texts, batch=64, world=1, rank=0, policy="lpt", steps_per_id=6,
+                 max_steps=3000, phase_seed=0, device=None):
+        self.model, self.ap = model, ap
+        self.r = model.decoder.r
+        lengths = np.asarray(lengths)
+        batches = plan_batches(lengths, batch)
+        self.items = []
+        self.frames = 0          # frames that count: sum over utterances of their own steps * r
+        self.frames_padded = 0   # frames the decoder computes: rows * steps of the batch * r
+        self.n_utts = 0
+        dev = device if device is not None else model.device
+        for bi in deal(batches, lengths, world, policy)[rank]:
+            idx = batches[bi]
+            ids, lens = pad_batch(texts, idx)
+            steps_b = np.minimum(max_steps, steps_per_id * lens)
+            steps = int(steps_b.max())
+            n_frames = (steps_b * self.r).astype(np.int32)
+            gen = torch.Generator(device=dev).manual_seed(phase_seed + int(bi))
+            phase = torch.rand(len(idx), steps * self.r, 1025, device=dev, generator=gen)
+            self.items.append(dict(batch_index=int(bi), idx=idx, ids=torch.as_tensor(ids).to(dev),
+                                   lens=torch.as_tensor(lens.astype(np.int32)).to(dev), steps=steps,
+                                   n_frames=torch.as_tensor(n_frames).to(dev), phase=phase))
+            self.frames += int(n_frames.sum())
+            self.frames_padded += len(idx) * steps * self.r
+            self.n_utts += len(idx)
+
+    def run(self, keep=False):
+        """One pass over the shard: encoder, decoder, postnet, mel-to-linear, Griffin-Lim per batch.
+        With `keep` returns {utterance index: (mel [F,80], wav [hop*(F-1)])} on the host."""
+        m, ap = self.model, self.ap
+        out = {}
+        for it in self.items:
+            enc = m.encode(it["ids"], it["lens"])
+            mel, align, stop, n_steps, steps = m.decode(enc, it["lens"], fixed_steps=it["steps"])
+            post = m.postnet(mel, it["n_frames"])
+            wav = ap.griffin_lim_batch(ap.spec_to_mag(post), it["phase"], it["n_frames"])
+            if keep:
+                nf = it["n_frames"].cpu().numpy()
+                post_h, wav_h = post.cpu().numpy(), wav.cpu().numpy()
+                for row, i in enumerate(it["idx"]):
+                    F = int(nf[row])
+                    out[int(i)] = (post_h[row, :F].copy(), wav_h[row, :ap.hop_length * max(F - 1, 0)].copy())
+        return out if keep else None
+
+
+def gather_rank_stats(values, dist=None, device=None):
+    """[world, len(values)] float64 array with every rank's `values` (reporting only: frame counts and busy
+    times, a few numbers per rank)."""
+    v = torch.tensor([float(x) for x in values], dtype=torch.float64, device=device if device is not None else "cpu")
+    if dist is None:
+        return v.cpu().numpy()[None]
+    bufs = [torch.empty_like(v) for _ in range(dist.get_world_size())]
+    dist.all_gather(bufs, v)
+    return torch.stack(bufs).cpu().numpy()

@@ -1529,6 +1529,7 @@ struct ttsx_t2_decoder {
   RunCtx* rc_host;   // pinned staging copy
   int* host_flag;    // pinned
   int steps_done;    // host mirror of rc.base
+  int last_launched; // decoder steps the last run() enqueued (>= the steps any utterance needed)
   bool begun;
   // cached chunk graph
   hipGraphExec_t graph;
@@ -2456,9 +2457,15 @@ extern "C" int ttsx_t2_decoder_run(ttsx_t2_decoder* d, const float* enc, const i
   for (int b = 0; b < B; ++b) run = std::max(run, (int)host[b]);
   if (fixed_steps) run = launched;
   if (steps_run_host) *steps_run_host = run;
+  d->last_launched = launched;
   d->steps_done = run;
   d->begun = false;  // the state belongs to a finished batch
   return TTSX_OK;
+}
+
+extern "C" int ttsx_t2_decoder_steps_launched(const ttsx_t2_decoder* d) {
+  TTSX_ARG(d, "ttsx_t2_decoder_steps_launched: null handle");
+  return d->last_launched;
 }
 
 // ====================================================================== encoder BiLSTM

@@ -77,7 +77,14 @@ def integers(seed, name, shape, lo, hi):
 # --------------------------------------------------------------------------
 T2_GAINS = dict(lstm=2.5, proj=6.0, v=10.0, loc=10.0, query=3.0, stop=8.0,
                 inputs=1.0, prenet=1.0, conv=1.0, emb=3.0, enc_lstm=4.0,
-                stop_bias=-7.8)
+                stop_bias=-7.8, stop_stream=None)
+
+# Gains of a checkpoint whose stop token fires late: with the default stopnet weights the stop logit peaks
+# during the first 15 steps of any text and never comes back, so a free run ends there.  Stopnet weights
+# drawn from hash stream 18 give a logit that rises slowly to a hump around step 355 of the 100-id
+# utterance t2_text_ids(99, 1, 100); with this bias it crosses 0.7 near step 309, on a slope of 0.01 per
+# step, so the stop step is data-dependent and robust to rounding.
+T2_LATE_STOP_GAINS = dict(stop_stream=18, stop_bias=-20.65)
 
 
 def _xavier(seed, name, shape, gain=1.0):
@@ -170,8 +177,9 @@ def t2_state_dict(seed=0, num_chars=129, r_init=7, prenet_type="bn", gains=None,
         seed, "dec.proj", (80 * r_init, 1536), g["proj"])
     sd["decoder.linear_projection.linear_layer.bias"] = uniform(
         seed, "dec.proj.b", (80 * r_init,), -0.05, 0.05)
+    stop_name = "dec.stop" if g["stop_stream"] is None else "dec.stop/%d" % g["stop_stream"]
     sd["decoder.stopnet.1.linear_layer.weight"] = _xavier(
-        seed, "dec.stop", (1, 1024 + 80 * r_init), g["stop"])
+        seed, stop_name, (1, 1024 + 80 * r_init), g["stop"])
     sd["decoder.stopnet.1.linear_layer.bias"] = np.full((1,), g["stop_bias"], dtype=np.float32)
     # postnet
     chans = [80, 512, 512, 512, 512, 80]

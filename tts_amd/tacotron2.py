@@ -323,6 +323,10 @@ class Tacotron2:
         s = steps_run.value
         return mel[:, :s * r], align[:, :s], stop[:, :s], n_steps, s
 
+    def last_steps_launched(self):
+        """Decoder steps the last decode() enqueued (at least the steps any utterance needed)."""
+        return int(_lib.load().ttsx_t2_decoder_steps_launched(self._dec_handle))
+
     @torch.no_grad()
     def postnet(self, mel, n_frames=None):
         """mel + Postnet(mel) (Tacotron2/TTS/models.py:809-810) on [B,F,80]."""
