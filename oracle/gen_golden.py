@@ -9,6 +9,7 @@ Usage (from the repo root, in the container that mounts /root/reference):
     python oracle/gen_golden.py t2audio # AudioProcessor pieces that run without librosa
     python oracle/gen_golden.py t1      # Tacotron (v1) model fixtures
     python oracle/gen_golden.py text    # symbol tables, cleaners, number speller, id sequences
+    python oracle/gen_golden.py config  # the three config files as the reference's loaders parse them
 
 Each family runs in its own process because both reference trees define a
 top-level package called `TTS`.  The reference never travels to the GPU box:
@@ -356,6 +357,40 @@ def gen_text():
     print("text_cases: %d symbols, %d phonemes" % (len(U.symbols), len(U.phonemes)))
 
 
+# ------------------------------------------------------------------ config files
+def gen_config():
+    """The reference's three config files as its own loaders parse them (load_config strips `//` comments and
+    backslash-newlines, Tacotron2/TTS/utils.py:1040-1048; conf.json goes through json.load into Map,
+    Tacotron2/Tacotron2.py:41-42), plus what the reference's AudioProcessor derives from each audio block
+    (n_fft, hop_length, win_length: _stft_parameters, Tacotron2/TTS/utils.py:853-860 / Tacotron/TTS/utils.py:127-134).
+    The fixture holds parsed values only, not the files' text."""
+    _register_placeholders()
+    out = {}
+    for tree in ("Tacotron2", "Tacotron"):
+        for m in [k for k in sys.modules if k == "TTS" or k.startswith("TTS.")]:
+            del sys.modules[m]
+        sys.path.insert(0, os.path.join(REF, tree))
+        from TTS import utils as U  # the reference implementation
+        cfg = U.load_config(os.path.join(REF, tree, "models", "config.json"))
+        import contextlib
+        import io
+        with contextlib.redirect_stdout(io.StringIO()):
+            ap = U.AudioProcessor(**cfg.audio)
+        out[tree + "/models/config.json"] = dict(parsed=dict(cfg), derived=dict(
+            n_fft=int(ap.n_fft), hop_length=int(ap.hop_length), win_length=int(ap.win_length)))
+        if tree == "Tacotron2":
+            with open(os.path.join(REF, tree, "conf.json"), "rt") as f:
+                args = U.Map(json.load(f))
+            out["Tacotron2/conf.json"] = dict(parsed=dict(args), missing_key_is_none=args.no_such_key is None)
+        sys.path.pop(0)
+    # kept inside the package: tts_amd.config.repo_config() serves these values as the repo's configuration
+    with open(os.path.join(ROOT, "tts_amd", "ref_configs.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    for k, v in out.items():
+        print(k, len(v["parsed"]), "keys", v.get("derived", ""))
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    {"t2": gen_t2, "t2long": gen_t2long, "t2v": gen_t2v, "t2audio": gen_t2audio, "t1": gen_t1, "text": gen_text}[sys.argv[1]]()
+    {"t2": gen_t2, "t2long": gen_t2long, "t2v": gen_t2v, "t2audio": gen_t2audio, "t1": gen_t1, "text": gen_text,
+     "config": gen_config}[sys.argv[1]]()

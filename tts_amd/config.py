@@ -1,35 +1,79 @@
-"""Config helpers with the reference's behaviour (Tacotron2/TTS/utils.py:1007-1048)."""
+"""Config helpers with the reference's behaviour (Tacotron2/TTS/utils.py:1007-1048).
+
+`ref_configs.json` next to this file holds the PARSED content of the reference's three config files
+(Tacotron2/models/config.json, Tacotron/models/config.json, Tacotron2/conf.json) as the reference's own
+loaders return them; oracle/gen_golden.py writes it by calling those loaders.
+"""
 import json
+import os
 import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 class AttrDict(dict):
+    """dict whose keys are attributes too (utils.py:1007-1010): a missing key raises."""
+
     def __init__(self, *args, **kwargs):
         super(AttrDict, self).__init__(*args, **kwargs)
         self.__dict__ = self
 
 
+class Map(dict):
+    """The server's conf.json wrapper (utils.py:1012-1038): attribute access, a missing key reads as None
+    (Synthesizer relies on that for `wavernn_path`, Tacotron2/TTS/synthesizer.py:37-39)."""
+
+    def __init__(self, *args, **kwargs):
+        super(Map, self).__init__()
+        for src in list(args) + [kwargs]:
+            if isinstance(src, dict):
+                for k, v in src.items():
+                    self[k] = v
+
+    def __getattr__(self, attr):
+        return self.get(attr)
+
+    def __setattr__(self, key, value):
+        self[key] = value
+
+    def __delattr__(self, key):
+        del self[key]
+
+
+_CONTINUATION = re.compile(r"\\\n")
+_COMMENT = re.compile(r"//.*\n")
+
+
+def parse_config(text):
+    """JSON with `//` comments and backslash-newline continuations (utils.py:1040-1048).  As in the reference
+    a comment runs from `//` to the end of its line wherever the `//` stands - also inside a string value,
+    which is why the reference's config writes its URL with escaped slashes (tcp:\\/\\/localhost)."""
+    return AttrDict(json.loads(_COMMENT.sub("\n", _CONTINUATION.sub("", text))))
+
+
 def load_config(config_path):
-    """JSON with `//` comments and backslash-newline continuations, as the reference parses it
-    (utils.py:1040-1048)."""
-    config = AttrDict()
     with open(config_path, "r") as f:
-        input_str = f.read()
-    input_str = re.sub(r'\\\n', '', input_str)
-    input_str = re.sub(r'//.*\n', '\n', input_str)
-    config.update(json.loads(input_str))
-    return config
+        return parse_config(f.read())
+
+
+def load_server_config(path):
+    """conf.json as Tacotron2/Tacotron2.py:41-42 reads it: plain JSON into a Map."""
+    with open(path, "rt") as f:
+        return Map(json.load(f))
+
+
+def _ref_configs():
+    with open(os.path.join(_HERE, "ref_configs.json")) as f:
+        return json.load(f)
+
+
+def repo_config(name="Tacotron2/models/config.json"):
+    """The parsed content of one of the reference's config files: 'Tacotron2/models/config.json' and
+    'Tacotron/models/config.json' as AttrDict, 'Tacotron2/conf.json' as Map."""
+    parsed = _ref_configs()[name]["parsed"]
+    return Map(parsed) if name.endswith("conf.json") else AttrDict(parsed)
 
 
 def tacotron2_repo_config():
-    """The hyper-parameters of the repo's Tacotron2 model config that the serving path reads
-    (values of Tacotron2/models/config.json:9-29, 39, 81-92)."""
-    return AttrDict(
-        model="Tacotron2", r=7, prenet_type="bn", prenet_dropout=False, attention_type="original",
-        attention_heads=5, attention_norm="sigmoid", windowing=False, use_forward_attn=False,
-        forward_attn_mask=False, transition_agent=False, location_attn=True, bidirectional_decoder=False,
-        separate_stopnet=True, use_gst=False, use_phonemes=True, enable_eos_bos_chars=False,
-        audio=dict(num_mels=80, num_freq=1025, sample_rate=22050, frame_length_ms=50, frame_shift_ms=12.5,
-                   preemphasis=0.98, min_level_db=-100, ref_level_db=20, power=1.5, griffin_lim_iters=60,
-                   signal_norm=True, symmetric_norm=True, max_norm=4, clip_norm=True, mel_fmin=0.0,
-                   mel_fmax=8000.0, do_trim_silence=True))
+    """The repo's Tacotron2 model config (Tacotron2/models/config.json) as `load_config` returns it."""
+    return repo_config("Tacotron2/models/config.json")
