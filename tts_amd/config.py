@@ -2,7 +2,7 @@
 
 `ref_configs.json` next to this file holds the PARSED content of the reference's three config files
 (Tacotron2/models/config.json, Tacotron/models/config.json, Tacotron2/conf.json) as the reference's own
-loaders return them; oracle/gen_golden.py writes it by calling those loaders.
+loaders return them (written by the golden-vector generator, which calls those loaders in the build container).
 """
 import json
 import os
