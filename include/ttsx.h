@@ -17,7 +17,11 @@
  *     the header needs no HIP include); calls that return host-visible
  *     results synchronise that stream before returning and say so;
  *   - fp32 everywhere; weights are handed over in the reference's own
- *     state_dict layouts and packed once at create time.
+ *     state_dict layouts and packed once at create time;
+ *   - per-utterance length arrays (enc_len, lengths, n_frames, n_samples) are
+ *     read on the device and clamped there to the range the call's shape
+ *     allows (0 or 1 .. T / F / pitch): an out-of-range entry shortens or
+ *     lengthens nothing beyond the buffers of the call.
  */
 #ifndef TTSX_H
 #define TTSX_H
@@ -374,20 +378,37 @@ typedef struct {
 int ttsx_spec_to_mag(const float* spec, const float* inv_basis, int B, int F, int C, int n_freq,
                      const ttsx_audio_params* ap, float* mag, void* stream);
 
-/* Batched Griffin-Lim + de-emphasis.
+/* Vocoder handle: the twiddle / window tables of one STFT geometry and the scratch signals Griffin-Lim ping-pongs
+ * between, on the device that is current at create.  Calls on a handle are enqueued on the caller's stream and
+ * do NOT synchronise (results are stream-ordered); scratch grows on demand (growing waits for the stream).  One
+ * handle serves one caller at a time; handles share nothing, so callers with a handle each can overlap.
+ * The library keeps no vocoder state outside handles. */
+typedef struct ttsx_vocoder ttsx_vocoder;
+int ttsx_vocoder_create(const ttsx_stft_params* sp, void* stream, ttsx_vocoder** out);
+int ttsx_vocoder_destroy(ttsx_vocoder* v);
+
+/* Batched Griffin-Lim + de-emphasis (AudioProcessor._griffin_lim, utils.py:922-929, + apply_inv_preemphasis).
  *   mag        [B,F,n_freq] target magnitudes (frame-major)
  *   init_phase [B,F,n_freq] initial phase as a fraction of a turn in [0,1) (the reference
  *              draws it from the global NumPy RNG, utils.py:923)
- *   n_frames   [B] int32 valid frames per utterance or NULL (= F)
+ *   n_frames   [B] int32 valid frames per utterance or NULL (= F); values outside 0..F are clamped
  *   iters      griffin_lim_iters (60)
  *   preemph    de-emphasis coefficient (0.98); 0 skips the filter; |preemph| <= 0.9899 (the filter runs as a blocked
  *              scan that cuts its impulse response off after 2048 taps: |a|^2048 < 1e-9)
  *   wav        [B, hop*(F-1)] ; utterance b holds hop*(n_frames[b]-1) samples, rest zero   */
+int ttsx_vocoder_griffin_lim(ttsx_vocoder* v, const float* mag, const float* init_phase, const int32_t* n_frames,
+                             int B, int F, int iters, float preemph, float* wav, void* stream);
+
+/* Unit-level entry points (librosa.stft / librosa.istft semantics, center=True; utils.py:931-942).
+ *   y  [B, hop*(F-1)]   spec_re/spec_im [B,F,n_freq]                                      */
+int ttsx_vocoder_stft(ttsx_vocoder* v, const float* y, int B, int F, float* spec_re, float* spec_im, void* stream);
+int ttsx_vocoder_istft(ttsx_vocoder* v, const float* spec_re, const float* spec_im, int B, int F, float* y,
+                       void* stream);
+
+/* One-shot forms of the three calls above: tables and scratch are allocated for the call and released before it
+ * returns, which synchronises `stream`.  For occasional calls; a serving loop keeps a handle. */
 int ttsx_griffin_lim(const float* mag, const float* init_phase, const int32_t* n_frames, int B, int F,
                      const ttsx_stft_params* sp, int iters, float preemph, float* wav, void* stream);
-
-/* Unit-level entry points (librosa.stft / librosa.istft semantics, center=True).
- *   y  [B, hop*(F-1)]   spec_re/spec_im [B,F,n_freq]                                      */
 int ttsx_stft(const float* y, int B, int F, const ttsx_stft_params* sp, float* spec_re, float* spec_im,
               void* stream);
 int ttsx_istft(const float* spec_re, const float* spec_im, int B, int F, const ttsx_stft_params* sp,
@@ -400,8 +421,9 @@ int ttsx_istft(const float* spec_re, const float* spec_im, int B, int F, const t
  *   wav        [B,pitch] float32 waveforms, n_samples [B] int32 valid samples per sentence or NULL (= pitch)
  *   window_length = int(sample_rate * 0.8), hop_length = int(window_length / 4), threshold = 10^(-40/20)
  *   do_trim    0: keep every sentence whole
- *   endpoints  [B] int32 out, offsets [B+1] int32 out (start of every sentence in pcm; total at [B])
- *   pcm        [capacity] int16 out, capacity >= B*(pitch+gap);  *total_host = samples written,
+ *   endpoints  [B] int32 out, offsets [B+2] int32 out (start of every sentence in pcm; total at [B]; [B+1] is
+ *              working space of the call: no device memory is allocated)
+ *   pcm        [capacity] int16 out, capacity >= B*(pitch+gap), at most 2^31-1;  *total_host = samples written,
  *              *peak_host = max |sample| before scaling.  Synchronises `stream`.                       */
 int ttsx_request_tail(const float* wav, const int32_t* n_samples, int B, int pitch, int window_length, int hop_length,
                       float threshold, int gap, int do_trim, int32_t* endpoints, int32_t* offsets, int16_t* pcm,

@@ -69,3 +69,56 @@ def test_griffin_lim_is_consistent():
     # spectral convergence improves over the iterations
     err = [np.linalg.norm(np.abs(a._stft(v)) - S) / np.linalg.norm(S) for v in (ys[0], ys[-1])]
     assert err[1] < err[0]
+
+
+def test_package_host_helpers_match_reference_fixture():
+    """The NumPy-in / NumPy-out helpers AudioProcessor keeps under the reference's names, against values the
+    reference itself produced (no GPU involved)."""
+    import io
+    from tts_amd.audio import AudioProcessor
+    for name, v1 in (("t2_audio_pieces.npz", False), ("t1_audio_pieces.npz", True)):
+        g = np.load(os.path.join(GOLDEN, name))
+        meta = json.loads(str(g["meta"]))
+        ap = AudioProcessor(verbose=False, tacotron_v1=v1, **meta)
+        assert [ap.n_fft, ap.hop_length, ap.win_length] == g["params"].tolist()
+        den = ap._denormalize(g["x"])
+        np.testing.assert_array_equal(den, g["denorm"])
+        np.testing.assert_array_equal(ap._db_to_amp(den + ap.ref_level_db), g["amp"])
+        if v1:
+            continue
+        np.testing.assert_array_equal(ap.apply_inv_preemphasis(g["y"]), g["deemph"])
+        assert ap.find_endpoint(g["wav"]) == int(g["endpoint"])
+        assert ap.find_endpoint(g["wav"][:100]) == 100
+        buf = io.BytesIO()
+        ap.save_wav(g["deemph"], buf)
+        assert np.array_equal(np.frombuffer(buf.getvalue(), dtype=np.uint8), g["wav_bytes"])
+
+
+def test_mel_filterbank_has_the_published_slaney_properties():
+    """PARITY UNPINNED: librosa.filters.mel is not importable here and the reference holds no vectors for it.
+    What can be checked without it are the properties the published Slaney construction defines, on the
+    oracle's filterbank and on the package's (two separately written functions; the last assertion only says
+    that they agree with each other, which pins neither)."""
+    from tts_amd import audio
+    # mel scale: 200/3 Hz per mel below 1 kHz, 27 mels per factor 6.4 above
+    assert abs(float(audio._hz_to_mel(1000.0)) - 15.0) < 1e-12 and abs(float(audio._hz_to_mel(6400.0)) - 42.0) < 1e-9
+    assert abs(float(audio._mel_to_hz(42.0)) - 6400.0) < 1e-6 and abs(float(audio._mel_to_hz(7.5)) - 500.0) < 1e-9
+    orc = ao.AudioOracle(**ao.T2_AUDIO)
+    for fb in (orc._build_mel_basis(), audio.mel_filterbank(22050, 2048, 80, 0.0, 8000.0)):
+        assert fb.shape == (80, 1025) and fb.dtype == np.float32 and (fb >= 0).all()
+        freqs = np.linspace(0, 11025.0, 1025)
+        assert fb[:, freqs > 8000.0].max() == 0.0                       # nothing above fmax
+        peaks = fb.argmax(axis=1)
+        assert (np.diff(peaks) > 0).all()                               # centres increase
+        for row in fb:                                                  # each filter is one rise and one fall
+            nz = np.nonzero(row)[0]
+            assert (np.diff(nz) == 1).all()
+            k = row.argmax()
+            assert (np.diff(row[nz[0]:k + 1]) >= 0).all() and (np.diff(row[k:nz[-1] + 1]) <= 0).all()
+        # Slaney normalisation: every triangle has unit area in Hz (up to the sampling of the triangle)
+        area = fb.sum(axis=1) * (11025.0 / 1024)
+        assert np.abs(area - 1.0).max() < 0.15 and abs(area[40:].mean() - 1.0) < 0.01
+        # centre of filter i is mel point i+1 of 82 equally spaced mel points between 0 and 8000 Hz
+        mel_pts = audio._mel_to_hz(np.linspace(audio._hz_to_mel(0.0), audio._hz_to_mel(8000.0), 82))
+        assert np.abs(freqs[peaks] - mel_pts[1:-1]).max() <= 11025.0 / 1024
+    np.testing.assert_array_equal(orc._build_mel_basis(), audio.mel_filterbank(22050, 2048, 80, 0.0, 8000.0))

@@ -91,6 +91,10 @@ def test_entry_points_reject_bad_arguments_before_any_device_call():
         "ttsx_griffin_lim": lambda: lib.ttsx_griffin_lim(None, one, None, 1, 8, byref(sp), 60, 1.0, one, None),
         "ttsx_stft": lambda: lib.ttsx_stft(None, 1, 8, byref(sp), one, one, None),
         "ttsx_istft": lambda: lib.ttsx_istft(None, one, 1, 8, byref(sp), one, None),
+        "ttsx_vocoder_create": lambda: lib.ttsx_vocoder_create(byref(sp), None, None),
+        "ttsx_vocoder_griffin_lim": lambda: lib.ttsx_vocoder_griffin_lim(None, one, one, None, 1, 8, 60, 0.98, one, None),
+        "ttsx_vocoder_stft": lambda: lib.ttsx_vocoder_stft(None, one, 1, 8, one, one, None),
+        "ttsx_vocoder_istft": lambda: lib.ttsx_vocoder_istft(None, one, one, 1, 8, one, None),
         "ttsx_request_tail": lambda: lib.ttsx_request_tail(None, None, 1, 100, 1024, 256, -40.0, 0, 0, one, one, one,
                                                            c_long(100), None, None, None),
     }

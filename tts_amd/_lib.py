@@ -124,6 +124,11 @@ PROTOTYPES = {
                                  c_void_p]),
     "ttsx_stft": (c_int, [_fp, c_int, c_int, POINTER(StftParams), _fp, _fp, c_void_p]),
     "ttsx_istft": (c_int, [_fp, _fp, c_int, c_int, POINTER(StftParams), _fp, c_void_p]),
+    "ttsx_vocoder_create": (c_int, [POINTER(StftParams), c_void_p, POINTER(c_void_p)]),
+    "ttsx_vocoder_destroy": (c_int, [c_void_p]),
+    "ttsx_vocoder_griffin_lim": (c_int, [c_void_p, _fp, _fp, _fp, c_int, c_int, c_int, c_float, _fp, c_void_p]),
+    "ttsx_vocoder_stft": (c_int, [c_void_p, _fp, c_int, c_int, _fp, _fp, c_void_p]),
+    "ttsx_vocoder_istft": (c_int, [c_void_p, _fp, _fp, c_int, c_int, _fp, c_void_p]),
     "ttsx_request_tail": (c_int, [_fp, _fp, c_int, c_int, c_int, c_int, c_float, c_int, c_int, _fp, _fp, _fp,
                                   c_long, POINTER(c_long), POINTER(c_float), c_void_p]),
 }

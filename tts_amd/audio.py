@@ -16,6 +16,8 @@ tree's STFT parameters (win_length from frame_length_ms, reflect padding).
 """
 import ctypes
 import io
+import threading
+import weakref
 
 import numpy as np
 import scipy.io.wavfile
@@ -89,6 +91,10 @@ class AudioProcessor(object):
                 print("\t | > {}:{}".format(key, value))
         self._device = device
         self._inv_basis_dev = None
+        self._tls = threading.local()       # one vocoder handle per calling thread (a handle serves one caller at a time)
+        self._handles = []
+        self._handles_mu = threading.Lock()
+        weakref.finalize(self, _destroy_vocoders, self._handles, self._handles_mu)
 
     # ---- host-side helpers, same arithmetic as the reference ---------------
     def _stft_parameters(self):
@@ -102,9 +108,17 @@ class AudioProcessor(object):
             win_length = int(hop_length * factor)
         return n_fft, hop_length, win_length
 
+    # ---- host-side mirrors of small reference helpers ---------------------------------------------------
+    # The serving path does this arithmetic on the device (ttsx_spec_to_mag: denormalise, dB -> amplitude,
+    # mel -> linear; ttsx_request_tail: endpoint search, int16 scaling; the de-emphasis kernel).  The methods
+    # below keep the reference's NumPy-in / NumPy-out helpers available under their names for callers that
+    # use them directly; tests pin them to values the reference itself produced.
     def save_wav(self, wav, path):
-        wav_norm = wav * (32767 / max(0.01, np.max(np.abs(wav))))
-        scipy.io.wavfile.write(path, self.sample_rate, wav_norm.astype(np.int16))
+        """utils.py:794-796: scale so that the peak (at least 0.01) maps to 32767, truncate to int16."""
+        wav = np.asarray(wav)
+        peak = np.abs(wav).max()
+        gain = 32767 / max(0.01, peak)
+        scipy.io.wavfile.write(path, self.sample_rate, (wav * gain).astype(np.int16))
 
     def _build_mel_basis(self):
         if self.mel_fmax is not None:
@@ -112,20 +126,21 @@ class AudioProcessor(object):
         return mel_filterbank(self.sample_rate, self.n_fft, self.num_mels, self.mel_fmin, self.mel_fmax)
 
     def _mel_to_linear(self, mel_spec):
-        inv_mel_basis = np.linalg.pinv(self._build_mel_basis())
-        return np.maximum(1e-10, np.dot(inv_mel_basis, mel_spec))
+        """utils.py:802-804 (the reference recomputes the pseudo-inverse on every call; so does this mirror -
+        the device path keeps it resident, `inv_mel_basis_device`)."""
+        return np.maximum(1e-10, np.linalg.pinv(self._build_mel_basis()) @ mel_spec)
 
     def _denormalize(self, S):
-        S_denorm = S
-        if self.signal_norm:
-            if self.symmetric_norm:
-                if self.clip_norm:
-                    S_denorm = np.clip(S_denorm, -self.max_norm, self.max_norm)
-                return ((S_denorm + self.max_norm) * -self.min_level_db / (2 * self.max_norm)) + self.min_level_db
-            if self.clip_norm:
-                S_denorm = np.clip(S_denorm, 0, self.max_norm)
-            return (S_denorm * -self.min_level_db / self.max_norm) + self.min_level_db
-        return S
+        """utils.py:834-851: normalised range [-max_norm, max_norm] (symmetric) or [0, max_norm] back to
+        [min_level_db, 0] dB, clipping first when clip_norm is set."""
+        if not self.signal_norm:
+            return S
+        lo, span = (-self.max_norm, 2 * self.max_norm) if self.symmetric_norm else (0, self.max_norm)
+        if self.clip_norm:
+            S = np.clip(S, lo, self.max_norm)
+        if self.symmetric_norm:
+            S = S + self.max_norm
+        return (S * -self.min_level_db / span) + self.min_level_db
 
     @staticmethod
     def _db_to_amp(x):
@@ -138,12 +153,18 @@ class AudioProcessor(object):
         return scipy.signal.lfilter([1], [1, -self.preemphasis], x)
 
     def find_endpoint(self, wav, threshold_db=-40, min_silence_sec=0.8):
-        window_length = int(self.sample_rate * min_silence_sec)
-        hop_length = int(window_length / 4)
+        """utils.py:944-951: end of the first window of `min_silence_sec` (stepped by a quarter of it, starting
+        one step in) whose maximum stays below the threshold; len(wav) if there is none."""
+        wav = np.asarray(wav)
+        window = int(self.sample_rate * min_silence_sec)
+        step = int(window / 4)
         threshold = self._db_to_amp(threshold_db)
-        for x in range(hop_length, len(wav) - window_length, hop_length):
-            if np.max(wav[x:x + window_length]) < threshold:
-                return x + hop_length
+        starts = np.arange(step, len(wav) - window, step)
+        if len(starts) == 0:
+            return len(wav)
+        for x in starts:
+            if wav[x:x + window].max() < threshold:
+                return int(x + step)
         return len(wav)
 
     # ---- device plumbing ----------------------------------------------------
@@ -157,6 +178,22 @@ class AudioProcessor(object):
     def _stft_params(self):
         return _lib.StftParams(self.n_fft, self.hop_length, self.win_length,
                                _lib.PAD_REFLECT if self.tacotron_v1 else _lib.PAD_CONSTANT)
+
+    def _vocoder(self):
+        """The calling thread's vocoder handle (tables + scratch on this AudioProcessor's device), created on
+        first use.  Request threads that share an AudioProcessor get a handle each, so their Griffin-Lim calls
+        can overlap on the GPU."""
+        h = getattr(self._tls, "handle", None)
+        if h is None:
+            lib = _lib.load()
+            h = ctypes.c_void_p()
+            with torch.cuda.device(self._dev()):
+                _lib.check(lib.ttsx_vocoder_create(self._stft_params(), _lib.current_stream(), ctypes.byref(h)),
+                           "ttsx_vocoder_create")
+            self._tls.handle = h
+            with self._handles_mu:
+                self._handles.append(h)
+        return h
 
     def _audio_params(self):
         return _lib.AudioParams(int(bool(self.signal_norm)), int(bool(self.symmetric_norm)),
@@ -191,12 +228,13 @@ class AudioProcessor(object):
         wav = torch.empty(B, self.hop_length * (Fr - 1), device=mag.device, dtype=torch.float32)
         if n_frames is not None:
             n_frames = n_frames.to(device=mag.device, dtype=torch.int32).contiguous()
-        sp = self._stft_params()
         pre = float(self.preemphasis) if (deemphasis and self.preemphasis != 0) else 0.0
+        if mag.device != self._dev():
+            raise ValueError("magnitudes live on %s, this AudioProcessor on %s" % (mag.device, self._dev()))
         with torch.cuda.device(mag.device):
-            _lib.check(lib.ttsx_griffin_lim(_lib.ptr(mag), _lib.ptr(init_phase), _lib.ptr(n_frames), B, Fr, sp,
-                                            int(self.griffin_lim_iters), pre, _lib.ptr(wav),
-                                            _lib.current_stream()), "ttsx_griffin_lim")
+            _lib.check(lib.ttsx_vocoder_griffin_lim(self._vocoder(), _lib.ptr(mag), _lib.ptr(init_phase),
+                                                    _lib.ptr(n_frames), B, Fr, int(self.griffin_lim_iters), pre,
+                                                    _lib.ptr(wav), _lib.current_stream()), "ttsx_vocoder_griffin_lim")
         return wav
 
     def request_tail(self, wav, n_samples=None, gap=10000, trim=True, threshold_db=-40, min_silence_sec=0.8):
@@ -213,7 +251,7 @@ class AudioProcessor(object):
         hop = int(window / 4)
         cap = B * (L + gap)
         endpoints = torch.empty(B, device=dev, dtype=torch.int32)
-        offsets = torch.empty(B + 1, device=dev, dtype=torch.int32)
+        offsets = torch.empty(B + 2, device=dev, dtype=torch.int32)
         pcm = torch.empty(cap, device=dev, dtype=torch.int16)
         total, peak = ctypes.c_long(0), ctypes.c_float(0.0)
         with torch.cuda.device(dev):
@@ -270,8 +308,8 @@ class AudioProcessor(object):
         re = torch.empty(1, Fr, self.num_freq, device=yd.device)
         im = torch.empty_like(re)
         with torch.cuda.device(yd.device):
-            _lib.check(lib.ttsx_stft(_lib.ptr(yd), 1, Fr, self._stft_params(), _lib.ptr(re), _lib.ptr(im),
-                                     _lib.current_stream()), "ttsx_stft")
+            _lib.check(lib.ttsx_vocoder_stft(self._vocoder(), _lib.ptr(yd), 1, Fr, _lib.ptr(re), _lib.ptr(im),
+                                             _lib.current_stream()), "ttsx_vocoder_stft")
         return (re[0].cpu().numpy() + 1j * im[0].cpu().numpy()).T.astype(np.complex64)
 
     def _istft(self, Y):
@@ -283,9 +321,18 @@ class AudioProcessor(object):
         im = torch.from_numpy(np.ascontiguousarray(Y.imag.T.astype(np.float32))).to(self._dev()).unsqueeze(0)
         y = torch.empty(1, self.hop_length * (Fr - 1), device=re.device)
         with torch.cuda.device(re.device):
-            _lib.check(lib.ttsx_istft(_lib.ptr(re), _lib.ptr(im), 1, Fr, self._stft_params(), _lib.ptr(y),
-                                      _lib.current_stream()), "ttsx_istft")
+            _lib.check(lib.ttsx_vocoder_istft(self._vocoder(), _lib.ptr(re), _lib.ptr(im), 1, Fr, _lib.ptr(y),
+                                              _lib.current_stream()), "ttsx_vocoder_istft")
         return y[0].cpu().numpy()
+
+
+def _destroy_vocoders(handles, mu):
+    with mu:
+        hs, handles[:] = list(handles), []
+    if hs:
+        lib = _lib.load()
+        for h in hs:
+            lib.ttsx_vocoder_destroy(h)
 
 
 def wav_bytes(ap, wav):

@@ -109,7 +109,7 @@ static __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvP p) {
     const long n = n0 + j * 32 + l31;
     bb[j] = (int)(n / p.F);
     ff[j] = (int)(n % p.F);
-    nf[j] = bb[j] < p.B ? (p.n_frames ? p.n_frames[bb[j]] : p.F) : 0;
+    nf[j] = bb[j] < p.B ? (p.n_frames ? min(max(p.n_frames[bb[j]], 0), p.F) : p.F) : 0;   // (lengths clamped to 0..F)
   }
 
   f32x16 acc[2][2];
@@ -198,7 +198,7 @@ static __global__ __launch_bounds__(256) void conv_mfma_small_kernel(ConvP p) {
   const int cb = blockIdx.y;
   const long n = (long)blockIdx.x * 32 + l31;
   const int bb = (int)(n / p.F), ff = (int)(n % p.F);
-  const int nf = bb < p.B ? (p.n_frames ? p.n_frames[bb] : p.F) : 0;
+  const int nf = bb < p.B ? (p.n_frames ? min(max(p.n_frames[bb], 0), p.F) : p.F) : 0;
   __shared__ f32x16 red[4][64];
   f32x16 acc;
 #pragma unroll

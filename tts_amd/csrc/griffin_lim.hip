@@ -21,7 +21,6 @@
 #include <math.h>
 #include <stdlib.h>
 
-#include <mutex>
 #include <vector>
 
 #include "common.h"
@@ -33,14 +32,6 @@ constexpr int WP = 1104;          // row pitch of the windowed-frame buffer (flo
 constexpr int FR_PER_WG = 4;      // frames (waves) per workgroup
 constexpr int LDS_PER_FR = MC + MC / 16;  // float2 per frame, padded by one every 16 against bank conflicts
 constexpr int OLA_MAXK = 8;       // frames that can overlap one sample: ceil(win / hop) <= 8
-
-struct Tables {
-  float2* tw;    // W_2048^m = exp(-2 pi i m / 2048), m = 0..1023
-  float* win[2]; // periodic Hann of win_length, zero-padded centrally to 2048
-  int win_len[2];
-};
-Tables g_tab = {nullptr, {nullptr, nullptr}, {0, 0}};
-std::mutex g_tab_mu;
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
   return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
@@ -120,11 +111,7 @@ __device__ __forceinline__ void fft1024_tail(float2 (&v)[16], float2* s, const f
   for (int r = 0; r < 16; ++r) v[r] = s[bl + 68 * r];
   const int k = lane & 15;
 #pragma unroll
-#ifdef EXP_TWBCAST
-  for (int r = 1; r < 16; ++r) v[r] = cmul(v[r], tw1024<SIGN>(s_tw, 4 * r + k + z));
-#else
   for (int r = 1; r < 16; ++r) v[r] = cmul(v[r], tw1024<SIGN>(s_tw, 4 * k * r + z));
-#endif
   dft16<SIGN>(v);
   const int j0 = (lane >> 4) * 256 + k;
   const int bj = j0 + (j0 >> 4);  // pidx(j0 + 16 r) = bj + 17 r
@@ -236,11 +223,7 @@ __device__ __forceinline__ void frame_body(const FrameP& p, int b, int i, float2
           const int m = lane_a + 64 * r;
           const float2 w = s_win2[m + z];
           // the hop is odd in general: two 4-byte loads
-#ifdef EXP_NOLOAD
-          v[r] = make_float2((float)(m + z) * w.x, (float)(m - z) * w.y);
-#else
           v[r] = make_float2(src[2 * m] * w.x, src[2 * m + 1] * w.y);
-#endif
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -284,12 +267,8 @@ __device__ __forceinline__ void frame_body(const FrameP& p, int b, int i, float2
         continue;
       }
       float sk = 0.f, sm = 0.f;
-#ifdef EXP_NOMAG
-      if (KIND == K_GL_ITER || KIND == K_GL_INIT) sk = 1.f + z, sm = 2.f + z;
-#else
       if (KIND == K_GL_ITER) sk = mk[c], sm = mm[c];
       if (KIND == K_GL_INIT) sk = mg[k], sm = mg[mkk];
-#endif
       if (KIND == K_GL_ITER) {
         const float2 uk = unit_phase(Xk), um = unit_phase(Xm);
         Xk = make_float2(sk * uk.x, sk * uk.y);
@@ -363,11 +342,7 @@ __device__ __forceinline__ void frame_body(const FrameP& p, int b, int i, float2
         for (int r = 0; r < 4; ++r) {
           const int m = lane_s + 64 * c + 256 * r;  // complex index -> samples 2m, 2m+1
           const int n = 2 * m - lpe;
-#ifdef EXP_NOSTORE
-          if (n == -12345) {
-#else
           if (n >= 0 && n < WP) {
-#endif
             const float2 w = wn[4 * c + r];
             *reinterpret_cast<float2*>(dst + n) = make_float2(v[4 * c + r].x * scale * w.x, v[4 * c + r].y * scale * w.y);
           }
@@ -388,7 +363,7 @@ __global__ __launch_bounds__(64 * FR_PER_WG, 3) void frame_kernel(FrameP p) {
   const long total = (long)p.B * p.F;
   for (long fi = (long)blockIdx.x * FR_PER_WG + wave; fi < total; fi += (long)gridDim.x * FR_PER_WG) {
     const int b = (int)(fi / p.F), i = (int)(fi % p.F);
-    const int Fb = p.n_frames ? p.n_frames[b] : p.F;
+    const int Fb = p.n_frames ? min(max(p.n_frames[b], 0), p.F) : p.F;
     if (i >= Fb) continue;  // wave-uniform
     frame_body<KIND, false>(p, b, i, s_data[wave], s_tw, s_tw2, lane);
   }
@@ -422,7 +397,7 @@ __global__ __launch_bounds__(64 * FR_PER_WG, 3) void gl_fused_kernel(FusedP P) {
   // derived from it are wave-uniform and keeps them in scalar registers)
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int b = blockIdx.y;
-  const int Fb = p.n_frames ? p.n_frames[b] : p.F;
+  const int Fb = p.n_frames ? min(max(p.n_frames[b], 0), p.F) : p.F;
   const int L = q.hop * (Fb - 1), Lmax = q.hop * (p.F - 1);
   const int shift = q.lpad - (q.lpad & ~1);
   const int K = (q.win + q.hop - 1) / q.hop;
@@ -548,7 +523,7 @@ __global__ __launch_bounds__(320) void ola_kernel(float* __restrict__ out, const
                                                   const int32_t* __restrict__ n_frames, int B, int F, FrameGeom q,
                                                   int n_slots) {
   const int b = blockIdx.y;
-  const int Fb = n_frames ? n_frames[b] : F;
+  const int Fb = n_frames ? min(max(n_frames[b], 0), F) : F;
   const int L = q.hop * (Fb - 1), Lmax = q.hop * (F - 1);
   const float* ywb = yw + (size_t)b * F * WP;
   const int K = (q.win + q.hop - 1) / q.hop;
@@ -587,7 +562,7 @@ __global__ __launch_bounds__(320) void ola_kernel(float* __restrict__ out, const
 __global__ void reflect_pad_kernel(float* __restrict__ ypad, const int32_t* __restrict__ n_frames, int B, int F,
                                    FrameGeom q) {
   const int b = blockIdx.y;
-  const int Fb = n_frames ? n_frames[b] : F;
+  const int Fb = n_frames ? min(max(n_frames[b], 0), F) : F;
   const int L = q.hop * (Fb - 1);
   if (L <= 1) return;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;  // 0 .. n_fft-1: first half = head pad, second = tail pad
@@ -650,7 +625,7 @@ __global__ __launch_bounds__(DE_SEGS_PER_WG) void deemph_kernel(float* __restric
   extern __shared__ float s_de[];
   __shared__ double s_end[DE_HALO + DE_SEGS_PER_WG];
   const int b = blockIdx.y, tid = threadIdx.x;
-  const int Fb = n_frames ? n_frames[b] : F;
+  const int Fb = n_frames ? min(max(n_frames[b], 0), F) : F;
   const int Lmax = hop * (F - 1), L = hop * (Fb - 1);
   const int base = (blockIdx.x * DE_SEGS_PER_WG - DE_HALO) * DE_SEG;  // first sample of the staged window
   const float* xb = x + (size_t)b * x_pitch;
@@ -764,36 +739,19 @@ __global__ __launch_bounds__(256) void spec_to_mag_kernel(MagP p) {
   }
 }
 
-int get_tables(const ttsx_stft_params* sp, const float2** tw, const float** winpad) {
-  std::lock_guard<std::mutex> lock(g_tab_mu);
-  if (!g_tab.tw) {
-    std::vector<float2> h(1024);
-    for (int m = 0; m < 1024; ++m) {
-      const double a = -2.0 * M_PI * (double)m / (double)NFFT;
-      h[m] = make_float2((float)cos(a), (float)sin(a));
-    }
-    TTSX_HIP(hipMalloc(reinterpret_cast<void**>(&g_tab.tw), 1024 * sizeof(float2)));
-    TTSX_HIP(hipMemcpy(g_tab.tw, h.data(), 1024 * sizeof(float2), hipMemcpyHostToDevice));
+// Twiddles W_2048^m (m < 1024) and the periodic Hann window of win_length (scipy.signal.get_window('hann', win,
+// fftbins=True)) zero-padded centrally to n_fft, evaluated in fp64 and rounded once.  Every entry point builds
+// its tables with this kernel, so that they are the same bits whichever way a caller comes in.
+__global__ void init_tables_kernel(float2* __restrict__ tw, float* __restrict__ winpad, int win_length) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < MC) {
+    const double a = -2.0 * M_PI * (double)i / (double)NFFT;
+    tw[i] = make_float2((float)cos(a), (float)sin(a));
   }
-  int slot = -1;
-  for (int s = 0; s < 2; ++s)
-    if (g_tab.win_len[s] == sp->win_length) slot = s;
-  if (slot < 0) {
-    slot = g_tab.win_len[0] == 0 ? 0 : 1;
-    if (g_tab.win[slot]) (void)hipFree(g_tab.win[slot]);
-    g_tab.win[slot] = nullptr;
-    // periodic Hann (scipy.signal.get_window('hann', win, fftbins=True)), padded centrally to n_fft
-    std::vector<float> h(NFFT, 0.f);
-    const int lpad = (NFFT - sp->win_length) / 2;
-    for (int n = 0; n < sp->win_length; ++n)
-      h[lpad + n] = (float)(0.5 - 0.5 * cos(2.0 * M_PI * (double)n / (double)sp->win_length));
-    TTSX_HIP(hipMalloc(reinterpret_cast<void**>(&g_tab.win[slot]), NFFT * sizeof(float)));
-    TTSX_HIP(hipMemcpy(g_tab.win[slot], h.data(), NFFT * sizeof(float), hipMemcpyHostToDevice));
-    g_tab.win_len[slot] = sp->win_length;
+  if (i < NFFT) {
+    const int n = i - (NFFT - win_length) / 2;
+    winpad[i] = (n >= 0 && n < win_length) ? (float)(0.5 - 0.5 * cos(2.0 * M_PI * (double)n / (double)win_length)) : 0.f;
   }
-  *tw = g_tab.tw;
-  *winpad = g_tab.win[slot];
-  return TTSX_OK;
 }
 
 int check_stft_params(const ttsx_stft_params* sp, int B, int F) {
@@ -815,67 +773,24 @@ FrameGeom make_geom(const ttsx_stft_params* sp, int F) {
   return q;
 }
 
-// scratch shared by every call in the process: windowed frames and the padded signal
-struct Scratch {
-  float* yw;
-  float* ypad;   // two padded signals back to back (an iteration reads one and writes the other)
-  size_t cap_yw, cap_ypad;
-};
-Scratch g_scr = {nullptr, nullptr, 0, 0};
-std::mutex g_scr_mu;
-
-int ensure_scratch(size_t n_yw, size_t n_ypad) {
-  if (n_yw > g_scr.cap_yw) {
-    if (g_scr.yw) (void)hipFree(g_scr.yw);
-    g_scr.yw = nullptr, g_scr.cap_yw = 0;
-    TTSX_HIP(hipMalloc(reinterpret_cast<void**>(&g_scr.yw), n_yw * sizeof(float)));
-    g_scr.cap_yw = n_yw;
-  }
-  if (n_ypad > g_scr.cap_ypad) {
-    if (g_scr.ypad) (void)hipFree(g_scr.ypad);
-    g_scr.ypad = nullptr, g_scr.cap_ypad = 0;
-    TTSX_HIP(hipMalloc(reinterpret_cast<void**>(&g_scr.ypad), n_ypad * sizeof(float)));
-    g_scr.cap_ypad = n_ypad;
-  }
-  return TTSX_OK;
-}
-
-unsigned frame_grid(long total) { return (unsigned)std::min<long>((total + FR_PER_WG - 1) / FR_PER_WG, 256 * 12); }
-
-}  // namespace
-
-extern "C" int ttsx_spec_to_mag(const float* spec, const float* inv_basis, int B, int F, int C, int n_freq,
-                                const ttsx_audio_params* ap, float* mag, void* stream) {
-  TTSX_ARG(spec && mag && ap, "ttsx_spec_to_mag: null argument");
-  TTSX_ARG(B >= 1 && F >= 1 && n_freq >= 1, "ttsx_spec_to_mag: bad shape");
-  TTSX_ARG(inv_basis ? (C >= 1 && C <= 128) : (C == n_freq), "ttsx_spec_to_mag: C=%d invalid", C);
-  MagP p{spec, inv_basis, mag, C, n_freq, (long)B * F, *ap};
-  spec_to_mag_kernel<<<(unsigned)(((long)B * F + MAG_ROWS - 1) / MAG_ROWS), 256, 0, static_cast<hipStream_t>(stream)>>>(p);
-  TTSX_LAUNCH_CHECK();
-  return TTSX_OK;
-}
-
-extern "C" int ttsx_griffin_lim(const float* mag, const float* init_phase, const int32_t* n_frames, int B, int F,
-                                const ttsx_stft_params* sp, int iters, float preemph, float* wav, void* stream) {
+int check_gl_args(const float* mag, const float* init_phase, const float* wav, int iters, float preemph) {
   TTSX_ARG(mag && init_phase && wav, "ttsx_griffin_lim: null argument");
   TTSX_ARG(iters >= 0, "ttsx_griffin_lim: iters=%d", iters);
   // (the de-emphasis kernel cuts the filter's impulse response off after 2048 taps)
   TTSX_ARG(pow(fabs((double)preemph), 2048.0) < 1e-9,
            "ttsx_griffin_lim: preemphasis %g too close to 1 (|a|^2048 must be below 1e-9, i.e. |a| <= 0.9899)", preemph);
-  int rc = check_stft_params(sp, B, F);
-  if (rc) return rc;
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  const float2* tw;
-  const float* winpad;
-  rc = get_tables(sp, &tw, &winpad);
-  if (rc) return rc;
-  std::lock_guard<std::mutex> lock(g_scr_mu);
+  return TTSX_OK;
+}
+
+// The launches of a whole Griffin-Lim run on `st`: initial synthesis from the given phase, `iters` iterations
+// ping-ponging between the two padded signals ybuf[0] / ybuf[1] (B * q.LP floats each), de-emphasis into wav.
+// Every padded position of an utterance is written by each launch before the next one reads it, so the buffers
+// need not be cleared.  Nothing here allocates or synchronises.
+int enqueue_griffin_lim(const float2* tw, const float* winpad, float* const ybuf[2], const float* mag,
+                        const float* init_phase, const int32_t* n_frames, int B, int F, const ttsx_stft_params* sp,
+                        int iters, float preemph, float* wav, hipStream_t st) {
   const FrameGeom q = make_geom(sp, F);
   const size_t Lmax = (size_t)sp->hop_length * (F - 1);
-  const size_t n_pad = (size_t)B * q.LP;
-  rc = ensure_scratch(0, 2 * n_pad);
-  if (rc) return rc;
-  float* ybuf[2] = {g_scr.ypad, g_scr.ypad + n_pad};
   FusedP P{};
   P.f.mag = mag, P.f.phase01 = init_phase, P.f.n_frames = n_frames, P.f.tw = tw, P.f.winpad = winpad;
   P.f.B = B, P.f.F = F, P.f.q = q;
@@ -884,10 +799,10 @@ extern "C" int ttsx_griffin_lim(const float* mag, const float* init_phase, const
   P.n_rounds = ceil_div(n_slots, FR_PER_WG);
   P.n_halo = ceil_div(ceil_div(q.win, q.hop) - 1, FR_PER_WG);
   P.carry_len = q.win - q.hop;
-  // rounds per workgroup: long runs amortise the halo, short ones fill the chip (3 workgroups per CU)
-  // (as many workgroups as fit on the chip at once, so that no second, mostly empty wave of them runs)
-  static const int wgs_per_cu = getenv("TTSX_GL_WGS_PER_CU") ? atoi(getenv("TTSX_GL_WGS_PER_CU")) : 3;
-  P.C = std::max(1, ceil_div(P.n_rounds, std::max(1, 256 * wgs_per_cu / B)));
+  // rounds per workgroup: long runs amortise the halo, short ones fill the chip; as many workgroups as are
+  // resident at once (three per CU, bounded by LDS), so that no second, mostly empty wave of them runs
+  constexpr int WGS_PER_CU = 3, CUS = 256;
+  P.C = std::max(1, ceil_div(P.n_rounds, std::max(1, CUS * WGS_PER_CU / B)));
   const dim3 grid(ceil_div(P.n_rounds, P.C), B), refl_grid(NFFT / 256, B);
   const size_t smem = 2 * (size_t)std::max(P.carry_len, 1) * sizeof(float);
   const bool reflect = sp->pad_mode == TTSX_PAD_REFLECT;
@@ -914,17 +829,182 @@ extern "C" int ttsx_griffin_lim(const float* mag, const float* init_phase, const
   if (!direct) {
     // the IIR reads the trimmed part of the last padded signal
     const int nseg = (int)((Lmax + DE_SEG - 1) / DE_SEG);
-    static const hipError_t de_attr = hipFuncSetAttribute(
-        reinterpret_cast<const void*>(deemph_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-        (int)(DE_LDS_FLOATS * sizeof(float)));
-    TTSX_HIP(de_attr);
     deemph_kernel<<<dim3(ceil_div(nseg, DE_SEGS_PER_WG), B), DE_SEGS_PER_WG, DE_LDS_FLOATS * sizeof(float), st>>>(
         wav, ybuf[cur] + NFFT / 2, (size_t)q.LP, n_frames, B, F, sp->hop_length, preemph);
     TTSX_LAUNCH_CHECK();
   }
-  // the scratch is shared by every call in the process: finish before releasing the lock
-  TTSX_HIP(hipStreamSynchronize(st));
   return TTSX_OK;
+}
+
+// (the de-emphasis kernel stages ~74 KiB of samples per workgroup in dynamic LDS: the limit is raised for the
+// current device whenever a handle is created on it)
+int raise_deemph_lds() {
+  TTSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(deemph_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)(DE_LDS_FLOATS * sizeof(float))));
+  return TTSX_OK;
+}
+
+unsigned frame_grid(long total) { return (unsigned)std::min<long>((total + FR_PER_WG - 1) / FR_PER_WG, 256 * 12); }
+
+}  // namespace
+
+extern "C" int ttsx_spec_to_mag(const float* spec, const float* inv_basis, int B, int F, int C, int n_freq,
+                                const ttsx_audio_params* ap, float* mag, void* stream) {
+  TTSX_ARG(spec && mag && ap, "ttsx_spec_to_mag: null argument");
+  TTSX_ARG(B >= 1 && F >= 1 && n_freq >= 1, "ttsx_spec_to_mag: bad shape");
+  TTSX_ARG(inv_basis ? (C >= 1 && C <= 128) : (C == n_freq), "ttsx_spec_to_mag: C=%d invalid", C);
+  MagP p{spec, inv_basis, mag, C, n_freq, (long)B * F, *ap};
+  spec_to_mag_kernel<<<(unsigned)(((long)B * F + MAG_ROWS - 1) / MAG_ROWS), 256, 0, static_cast<hipStream_t>(stream)>>>(p);
+  TTSX_LAUNCH_CHECK();
+  return TTSX_OK;
+}
+
+
+// ------------------------------------------------------------------ vocoder handle
+// Everything a Griffin-Lim / STFT / ISTFT call needs beyond its arguments lives in the handle: the twiddle and
+// window tables of its STFT geometry and the scratch signals, all on the device that was current at create.
+// Calls on one handle are stream-ordered and do not synchronise; two handles never share anything, so two
+// request threads with a handle each can overlap their calls.
+struct ttsx_vocoder {
+  ttsx_stft_params sp;
+  int device;
+  float2* tw;      // W_2048^m, m < 1024
+  float* winpad;   // [2048]
+  float* yw;       // windowed frames of the stand-alone ISTFT
+  float* ypad;     // two padded signals back to back (an iteration reads one and writes the other)
+  size_t cap_yw, cap_ypad;
+};
+
+namespace {
+
+// Grow a scratch buffer.  The old one may still be read by work already enqueued on `st`: drain it first.
+int grow(float** buf, size_t* cap, size_t n, hipStream_t st) {
+  if (n <= *cap) return TTSX_OK;
+  if (*buf) {
+    TTSX_HIP(hipStreamSynchronize(st));
+    (void)hipFree(*buf);
+  }
+  *buf = nullptr, *cap = 0;
+  TTSX_HIP(hipMalloc(reinterpret_cast<void**>(buf), n * sizeof(float)));
+  *cap = n;
+  return TTSX_OK;
+}
+
+int check_device(const ttsx_vocoder* v, const char* who) {
+  int dev = -1;
+  TTSX_HIP(hipGetDevice(&dev));
+  TTSX_ARG(dev == v->device, "%s: the handle belongs to device %d, the current device is %d", who, v->device, dev);
+  return TTSX_OK;
+}
+
+}  // namespace
+
+extern "C" int ttsx_vocoder_create(const ttsx_stft_params* sp, void* stream, ttsx_vocoder** out) {
+  TTSX_ARG(out, "ttsx_vocoder_create: null argument");
+  int rc = check_stft_params(sp, 1, 2);
+  if (rc) return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  ttsx_vocoder* v = new ttsx_vocoder();
+  memset(v, 0, sizeof(*v));
+  ScopeExit on_fail([&] { (void)ttsx_vocoder_destroy(v); });
+  v->sp = *sp;
+  TTSX_HIP(hipGetDevice(&v->device));
+  TTSX_HIP(hipMalloc(reinterpret_cast<void**>(&v->tw), MC * sizeof(float2)));
+  TTSX_HIP(hipMalloc(reinterpret_cast<void**>(&v->winpad), NFFT * sizeof(float)));
+  init_tables_kernel<<<NFFT / 256, 256, 0, st>>>(v->tw, v->winpad, sp->win_length);
+  TTSX_LAUNCH_CHECK();
+  if ((rc = raise_deemph_lds())) return rc;
+  on_fail.dismiss();
+  *out = v;
+  return TTSX_OK;
+}
+
+extern "C" int ttsx_vocoder_destroy(ttsx_vocoder* v) {
+  if (!v) return TTSX_OK;
+  float* bufs[] = {reinterpret_cast<float*>(v->tw), v->winpad, v->yw, v->ypad};
+  for (float* b : bufs)
+    if (b) (void)hipFree(b);   // (hipFree waits for the device: nothing enqueued on the handle is cut short)
+  delete v;
+  return TTSX_OK;
+}
+
+extern "C" int ttsx_vocoder_griffin_lim(ttsx_vocoder* v, const float* mag, const float* init_phase,
+                                        const int32_t* n_frames, int B, int F, int iters, float preemph, float* wav,
+                                        void* stream) {
+  TTSX_ARG(v, "ttsx_vocoder_griffin_lim: null handle");
+  int rc = check_gl_args(mag, init_phase, wav, iters, preemph);
+  if (rc || (rc = check_stft_params(&v->sp, B, F)) || (rc = check_device(v, "ttsx_vocoder_griffin_lim"))) return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const size_t n_pad = (size_t)B * make_geom(&v->sp, F).LP;
+  if ((rc = grow(&v->ypad, &v->cap_ypad, 2 * n_pad, st))) return rc;
+  float* const ybuf[2] = {v->ypad, v->ypad + n_pad};
+  return enqueue_griffin_lim(v->tw, v->winpad, ybuf, mag, init_phase, n_frames, B, F, &v->sp, iters, preemph, wav, st);
+}
+
+extern "C" int ttsx_vocoder_stft(ttsx_vocoder* v, const float* y, int B, int F, float* spec_re, float* spec_im,
+                                 void* stream) {
+  TTSX_ARG(v && y && spec_re && spec_im, "ttsx_vocoder_stft: null argument");
+  int rc = check_stft_params(&v->sp, B, F);
+  if (rc || (rc = check_device(v, "ttsx_vocoder_stft"))) return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const FrameGeom q = make_geom(&v->sp, F);
+  if ((rc = grow(&v->ypad, &v->cap_ypad, (size_t)B * q.LP, st))) return rc;
+  pad_signal_kernel<<<dim3((unsigned)((q.LP + 255) / 256), B), 256, 0, st>>>(v->ypad, y, B, F, q);
+  TTSX_LAUNCH_CHECK();
+  FrameP p{};
+  p.ypad = v->ypad, p.spec_re = spec_re, p.spec_im = spec_im, p.tw = v->tw, p.winpad = v->winpad, p.B = B, p.F = F;
+  p.q = q;
+  frame_kernel<K_STFT><<<frame_grid((long)B * F), 64 * FR_PER_WG, 0, st>>>(p);
+  TTSX_LAUNCH_CHECK();
+  return TTSX_OK;
+}
+
+extern "C" int ttsx_vocoder_istft(ttsx_vocoder* v, const float* spec_re, const float* spec_im, int B, int F, float* y,
+                                  void* stream) {
+  TTSX_ARG(v && y && spec_re && spec_im, "ttsx_vocoder_istft: null argument");
+  int rc = check_stft_params(&v->sp, B, F);
+  if (rc || (rc = check_device(v, "ttsx_vocoder_istft"))) return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const FrameGeom q = make_geom(&v->sp, F);
+  const size_t Lmax = (size_t)v->sp.hop_length * (F - 1);
+  if ((rc = grow(&v->yw, &v->cap_yw, (size_t)B * F * WP, st))) return rc;
+  FrameP p{};
+  p.spec_re = const_cast<float*>(spec_re), p.spec_im = const_cast<float*>(spec_im), p.tw = v->tw, p.winpad = v->winpad;
+  p.B = B, p.F = F, p.yw_out = v->yw, p.q = q;
+  frame_kernel<K_ISTFT><<<frame_grid((long)B * F), 64 * FR_PER_WG, 0, st>>>(p);
+  TTSX_LAUNCH_CHECK();
+  const int n_slots = ceil_div(NFFT / 2 + (int)Lmax - q.lpad, q.hop);
+  ola_kernel<0><<<dim3(ceil_div(n_slots, OLA_SLOTS), B), 320, 0, st>>>(y, v->yw, v->winpad, nullptr, B, F, q, n_slots);
+  TTSX_LAUNCH_CHECK();
+  return TTSX_OK;
+}
+
+// ------------------------------------------------------------------ one-shot forms
+// The same three operations without a handle: tables and scratch are allocated for the call and released before
+// it returns (which waits for the device).  For occasional calls and unit tests; a serving loop keeps a handle.
+namespace {
+template <class F>
+int with_temporary_vocoder(const ttsx_stft_params* sp, void* stream, F body) {
+  ttsx_vocoder* v = nullptr;
+  int rc = ttsx_vocoder_create(sp, stream, &v);
+  if (rc) return rc;
+  rc = body(v);
+  if (!rc && hipStreamSynchronize(static_cast<hipStream_t>(stream)) != hipSuccess) {
+    ttsx_set_error("hipStreamSynchronize failed after a one-shot vocoder call");
+    rc = TTSX_ERR_HIP;
+  }
+  (void)ttsx_vocoder_destroy(v);
+  return rc;
+}
+}  // namespace
+
+extern "C" int ttsx_griffin_lim(const float* mag, const float* init_phase, const int32_t* n_frames, int B, int F,
+                                const ttsx_stft_params* sp, int iters, float preemph, float* wav, void* stream) {
+  int rc = check_gl_args(mag, init_phase, wav, iters, preemph);
+  if (rc || (rc = check_stft_params(sp, B, F))) return rc;
+  return with_temporary_vocoder(sp, stream, [&](ttsx_vocoder* v) {
+    return ttsx_vocoder_griffin_lim(v, mag, init_phase, n_frames, B, F, iters, preemph, wav, stream);
+  });
 }
 
 extern "C" int ttsx_stft(const float* y, int B, int F, const ttsx_stft_params* sp, float* spec_re, float* spec_im,
@@ -932,24 +1012,8 @@ extern "C" int ttsx_stft(const float* y, int B, int F, const ttsx_stft_params* s
   TTSX_ARG(y && spec_re && spec_im, "ttsx_stft: null argument");
   int rc = check_stft_params(sp, B, F);
   if (rc) return rc;
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  const float2* tw;
-  const float* winpad;
-  rc = get_tables(sp, &tw, &winpad);
-  if (rc) return rc;
-  std::lock_guard<std::mutex> lock(g_scr_mu);
-  const FrameGeom q = make_geom(sp, F);
-  rc = ensure_scratch(0, (size_t)B * q.LP);
-  if (rc) return rc;
-  pad_signal_kernel<<<dim3((unsigned)((q.LP + 255) / 256), B), 256, 0, st>>>(g_scr.ypad, y, B, F, q);
-  TTSX_LAUNCH_CHECK();
-  FrameP p{};
-  p.ypad = g_scr.ypad, p.spec_re = spec_re, p.spec_im = spec_im, p.tw = tw, p.winpad = winpad, p.B = B, p.F = F;
-  p.q = q;
-  frame_kernel<K_STFT><<<frame_grid((long)B * F), 64 * FR_PER_WG, 0, st>>>(p);
-  TTSX_LAUNCH_CHECK();
-  TTSX_HIP(hipStreamSynchronize(st));
-  return TTSX_OK;
+  return with_temporary_vocoder(sp, stream,
+                                [&](ttsx_vocoder* v) { return ttsx_vocoder_stft(v, y, B, F, spec_re, spec_im, stream); });
 }
 
 extern "C" int ttsx_istft(const float* spec_re, const float* spec_im, int B, int F, const ttsx_stft_params* sp,
@@ -957,24 +1021,6 @@ extern "C" int ttsx_istft(const float* spec_re, const float* spec_im, int B, int
   TTSX_ARG(y && spec_re && spec_im, "ttsx_istft: null argument");
   int rc = check_stft_params(sp, B, F);
   if (rc) return rc;
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  const float2* tw;
-  const float* winpad;
-  rc = get_tables(sp, &tw, &winpad);
-  if (rc) return rc;
-  std::lock_guard<std::mutex> lock(g_scr_mu);
-  const FrameGeom q = make_geom(sp, F);
-  const size_t Lmax = (size_t)sp->hop_length * (F - 1);
-  rc = ensure_scratch((size_t)B * F * WP, 0);
-  if (rc) return rc;
-  FrameP p{};
-  p.spec_re = const_cast<float*>(spec_re), p.spec_im = const_cast<float*>(spec_im), p.tw = tw, p.winpad = winpad;
-  p.B = B, p.F = F, p.yw_out = g_scr.yw, p.q = q;
-  frame_kernel<K_ISTFT><<<frame_grid((long)B * F), 64 * FR_PER_WG, 0, st>>>(p);
-  TTSX_LAUNCH_CHECK();
-  const int n_slots = ceil_div(NFFT / 2 + (int)Lmax - q.lpad, q.hop);
-  ola_kernel<0><<<dim3(ceil_div(n_slots, OLA_SLOTS), B), 320, 0, st>>>(y, g_scr.yw, winpad, nullptr, B, F, q, n_slots);
-  TTSX_LAUNCH_CHECK();
-  TTSX_HIP(hipStreamSynchronize(st));
-  return TTSX_OK;
+  return with_temporary_vocoder(sp, stream,
+                                [&](ttsx_vocoder* v) { return ttsx_vocoder_istft(v, spec_re, spec_im, B, F, y, stream); });
 }

@@ -35,7 +35,7 @@ __global__ void maxpool2_kernel(float* __restrict__ y, const float* __restrict__
   const size_t n = (size_t)B * F * C;
   if (i >= n) return;
   const int t = (int)((i / C) % F);
-  const int nf = n_frames ? n_frames[i / ((size_t)C * F)] : F;
+  const int nf = n_frames ? min(max(n_frames[i / ((size_t)C * F)], 0), F) : F;
   const float nxt = t + 1 < nf ? x[i + C] : 0.f;
   y[i] = fmaxf(x[i], nxt);
 }

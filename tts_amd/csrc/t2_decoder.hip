@@ -59,7 +59,8 @@ namespace {
 struct RunCtx {
   int base;      // decoder steps completed before the current chunk (state parity)
   int out_base;  // output row of the chunk's first step
-  int all_done;  // every utterance has emitted its stop frame (free-running mode)
+  int all_done;  // every utterance has emitted its stop frame (free-running mode): what the host polls
+  int done_at;   // index of the step during which that happened (INT_MAX before); see step_done()
   int n_done;
   int B, T, r, free_running;
   int max_steps;  // Tacotron (v1) stop rule: max_decoder_steps
@@ -71,6 +72,15 @@ struct RunCtx {
   float* stop;       // [B, stop_rows]
   int32_t* n_steps;  // [B]
 };
+
+// A step's launches do their arithmetic but keep nothing once every utterance has ended.  The test compares the
+// step's own index with the index of the step that raised the flag, so it cannot change under a launch: the
+// workgroup that detects the last stop shares its launch with the workgroups that write that step's frames, and
+// those must not see the flag (a plain flag would rest on the order in which workgroups are dispatched).
+constexpr int NEVER_DONE = 0x7fffffff;
+__device__ __forceinline__ int step_done(const RunCtx* c, int step_in_chunk) {
+  return c->base + step_in_chunk > c->done_at;
+}
 
 constexpr int ENC_DIM = 512, QUERY_DIM = 1024, DEC_DIM = 1024, PRENET_DIM = 256, ATT_DIM = 128;
 constexpr int MEL_DIM = 80, LOC_F = 32, LOC_K = 31;
@@ -340,7 +350,7 @@ __device__ __forceinline__ float epilogue_quad(const GemmP& p, int quad, int b, 
         if (s > cx->threshold && cx->n_steps[b] == 0) {
           cx->n_steps[b] = cx->base + p.step_in_chunk + 1;  // steps run so far, the stop frame included
           const int done = atomicAdd(&cx->n_done, 1) + 1;
-          if (cx->free_running && done == cx->B) cx->all_done = 1;
+          if (cx->free_running && done == cx->B) cx->done_at = cx->base + p.step_in_chunk, cx->all_done = 1;
         }
       }
     } else {
@@ -379,7 +389,7 @@ struct GemmOp {
   static __device__ __forceinline__ void run(const GemmP& p, int wg_in) {
     int wg = wg_in;
     if (KGW == 20) FA_MARK(8);
-    const int done = p.ctx->all_done;
+    const int done = step_done(p.ctx, p.step_in_chunk);
     const int ngrp = p.nrb / R;  // row-block groups of this launch
     int kpart = 0;
     if (MODE == MODE_PARTIAL && p.kparts > 1) {
@@ -519,7 +529,7 @@ template <int NB, int KGW, int MODE, int KP = 1>
 struct GemvOp {
   typedef GemmP P;
   static __device__ __forceinline__ void run(const GemmP& p, int wg) {
-    const int done = p.ctx->all_done;
+    const int done = step_done(p.ctx, p.step_in_chunk);
     int kpart = 0;
     if (KP > 1) kpart = wg / p.nrb, wg -= kpart * p.nrb, kpart += p.kpart0;
     const int kbase = kpart * (KGW * GEMM_WAVES);
@@ -676,7 +686,7 @@ struct EnergyOp {
   static constexpr int EN_CP = EN_TT / 16, EN_DP = EN_TT / 4;  // positions per thread in the conv / dense role
   typedef AttnP P;
   static __device__ __forceinline__ void run(const AttnP& p, int wg) {
-  const int done = p.ctx->all_done;
+  const int done = step_done(p.ctx, p.step_in_chunk);
   const int T = p.T, b = wg / p.gx, t0 = (wg % p.gx) * EN_TT, tid = threadIdx.x;
   __shared__ float s_a[2][EN_TT + 2 * ATT_PAD + 2];
   __shared__ __attribute__((aligned(16))) float s_cf[EN_TT][LOC_F];
@@ -782,7 +792,7 @@ struct ContextOp {
   typedef AttnP P;
   static __device__ __forceinline__ void run(const AttnP& p, int wg) {
   RunCtx* cx = p.ctx;
-  const int done = cx->all_done;
+  const int done = step_done(cx, p.step_in_chunk);
   const int T = p.T, b = wg / p.gx, bx = wg % p.gx, tid = threadIdx.x;
   const int len = p.len[b];
   extern __shared__ float s_dyn[];
@@ -958,7 +968,7 @@ struct AttnPostOp {
   typedef AttnP P;
   static __device__ __forceinline__ void run(const AttnP& p, int wg) {
     RunCtx* cx = p.ctx;
-    const int done = cx->all_done;
+    const int done = step_done(cx, p.step_in_chunk);
     const int T = p.T, b = wg, tid = threadIdx.x;
     const int len = p.len[b];
     extern __shared__ float s_dyn[];
@@ -1079,7 +1089,7 @@ struct GravesOp {
   typedef AttnP P;
   static __device__ __forceinline__ void run(const AttnP& p, int wg) {
     RunCtx* cx = p.ctx;
-    const int done = cx->all_done;
+    const int done = step_done(cx, p.step_in_chunk);
     const int T = p.T, b = wg, tid = threadIdx.x, K = p.graves_K;
     const int len = p.len[b];
     extern __shared__ float s_dyn[];
@@ -1151,7 +1161,7 @@ struct FusedAttnOp {
   typedef AttnP P;
   static __device__ __forceinline__ void run(const AttnP& p, int wg) {
     RunCtx* cx = p.ctx;
-    const int done = cx->all_done;
+    const int done = step_done(cx, p.step_in_chunk);
     const int T = p.T, b = wg, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int len = p.len[b];
     extern __shared__ float s_dyn[];
@@ -1437,8 +1447,8 @@ __global__ void pack_attn_frag_kernel(float* __restrict__ wlc_p, float* __restri
 }
 
 // ------------------------------------------------------------------ small utility kernels
+// (unconditional: steps enqueued after the last stop must keep counting, or step_done() would take them for live)
 __global__ void ctx_advance_kernel(RunCtx* c, int n) {
-  if (c->all_done) return;
   c->base += n;
   c->out_base += n;
 }
@@ -2333,7 +2343,7 @@ extern "C" int ttsx_t2_decoder_begin(ttsx_t2_decoder* d, const float* enc, const
   }
   RunCtx* h = d->rc_host;
   memset(h, 0, sizeof(*h));
-  h->B = B, h->T = T, h->r = d->proj_r, h->threshold = 2.f;
+  h->B = B, h->T = T, h->r = d->proj_r, h->threshold = 2.f, h->done_at = NEVER_DONE;
   d->steps_done = 0;
   d->begun = true;
   d->has_state = true;
@@ -2399,7 +2409,7 @@ extern "C" int ttsx_t2_decoder_step(ttsx_t2_decoder* d, const float* memory, int
   int rc = ensure_proj(d, r, st);
   if (rc) return rc;
   RunCtx* h = d->rc_host;
-  h->base = d->steps_done, h->out_base = 0, h->all_done = 0, h->n_done = 0;
+  h->base = d->steps_done, h->out_base = 0, h->all_done = 0, h->done_at = NEVER_DONE, h->n_done = 0;
   h->r = r, h->free_running = 0, h->threshold = 2.f;
   h->mel = frames, h->mel_rows = r, h->align = align, h->align_rows = 1, h->stop = stop, h->stop_rows = 1;
   // n_steps bookkeeping is not wanted here: point it at the energies scratch, never read back
@@ -2760,9 +2770,10 @@ struct MemShiftOp {
     float4* dst;
     int n;  // float4 elements
     RunCtx* ctx;
+    int step_in_chunk;
   };
   static __device__ __forceinline__ void run(const P& p, int wg) {
-    if (p.ctx->all_done) return;
+    if (step_done(p.ctx, p.step_in_chunk)) return;
     for (int i = wg * GEMM_THREADS + threadIdx.x; i < p.n; i += 4 * GEMM_THREADS) p.dst[i] = p.src[i];
   }
 };
@@ -2783,7 +2794,7 @@ struct T1StopOp {
   };
   static __device__ __forceinline__ void run(const P& p, int) {
     RunCtx* cx = p.ctx;
-    if (cx->all_done) return;
+    if (cx->all_done) return;   // (raised only by this op, which runs once per step: never under its own launch)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int b = wave; b < cx->B; b += GEMM_WAVES) {
       float acc = 0.f;
@@ -2798,7 +2809,9 @@ struct T1StopOp {
                          tn > cx->max_steps;
         if (end && cx->n_steps[b] == 0) {
           cx->n_steps[b] = tn;
-          if (atomicAdd(&cx->n_done, 1) + 1 == cx->B) cx->all_done = 1;
+          // this op rides along the first launch of step idx + 1, whose other workgroups are already running:
+          // that step completes (its output rows are masked), the ones after it keep nothing
+          if (atomicAdd(&cx->n_done, 1) + 1 == cx->B) cx->done_at = cx->base + p.idx + 1, cx->all_done = 1;
         }
       }
     }
@@ -2961,7 +2974,7 @@ int t1_enqueue_step(t1_steps* s, int B, int T, int i, int parity, hipStream_t st
   g.mem_new = mem_new, g.mem_keep = keep_quads;
   MemShiftOp::P ms{};
   ms.src = reinterpret_cast<const float4*>(mem_old) + (size_t)(s->odim / 4) * Bpad;
-  ms.dst = reinterpret_cast<float4*>(mem_new), ms.n = keep_quads * Bpad, ms.ctx = s->rc;
+  ms.dst = reinterpret_cast<float4*>(mem_new), ms.n = keep_quads * Bpad, ms.ctx = s->rc, ms.step_in_chunk = i;
   return t1_launch<MODE_MEL, 2, MemShiftOp>(s, B, g, ceil_div(s->odim, 16), ms, keep_quads > 0 ? 4 : 0, st);
 }
 
@@ -3154,7 +3167,7 @@ int t1_steps_run(t1_steps* s, const float* enc, const float* annot, const int32_
   memset(h, 0, sizeof(*h));
   const int rows = max_decoder_steps + 1;
   h->B = B, h->T = T, h->r = s->odim / MEL_DIM, h->free_running = 1, h->max_steps = max_decoder_steps;
-  h->mask_finished = 1;
+  h->mask_finished = 1, h->done_at = NEVER_DONE;
   h->mel = mel, h->mel_rows = rows * (s->odim / MEL_DIM), h->align = align, h->align_rows = rows;
   h->stop = stop, h->stop_rows = rows, h->n_steps = n_steps;
   TTSX_HIP(hipMemcpyAsync(s->rc, h, sizeof(RunCtx), hipMemcpyHostToDevice, st));

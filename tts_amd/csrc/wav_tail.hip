@@ -14,8 +14,9 @@ struct TailP {
   const float* wav;          // [B][pitch]
   const int32_t* n_samples;  // [B] or null
   int32_t* endpoints;        // [B]
-  int32_t* offsets;          // [B + 1] start of every sentence in the output, total at [B]
-  unsigned* peak_bits;       // bit pattern of max |sample| (non-negative floats order like unsigned ints)
+  int32_t* offsets;          // [B + 2] start of every sentence in the output, total at [B], peak word at [B + 1]
+  unsigned* peak_bits;       // = offsets + B + 1: bit pattern of max |sample| (non-negative floats order like
+                             // unsigned ints)
   int16_t* pcm;
   int B, pitch, window, hop, gap, do_trim;
   float threshold;
@@ -87,9 +88,11 @@ extern "C" int ttsx_request_tail(const float* wav, const int32_t* n_samples, int
            hop_length);
   TTSX_ARG(capacity >= (long)B * ((long)pitch + gap), "ttsx_request_tail: pcm capacity %ld < B*(pitch+gap) = %ld",
            capacity, (long)B * ((long)pitch + gap));
+  // (offsets are int32)
+  TTSX_ARG((long)B * ((long)pitch + gap) <= 2147483647L, "ttsx_request_tail: B*(pitch+gap) = %ld samples exceed int32",
+           (long)B * ((long)pitch + gap));
   hipStream_t st = static_cast<hipStream_t>(stream);
-  unsigned* peak_bits = nullptr;
-  TTSX_HIP(hipMalloc(reinterpret_cast<void**>(&peak_bits), sizeof(unsigned)));
+  unsigned* peak_bits = reinterpret_cast<unsigned*>(offsets + B + 1);
   TailP p{wav, n_samples, endpoints, offsets, peak_bits, pcm, B, pitch, window_length, hop_length, gap, do_trim, threshold};
   tail_init_kernel<<<ceil_div(B, 64), 64, 0, st>>>(p);
   const int n_cand = pitch / hop_length;
@@ -104,7 +107,6 @@ extern "C" int ttsx_request_tail(const float* wav, const int32_t* n_samples, int
   TTSX_HIP(hipMemcpyAsync(&total, offsets + B, sizeof(int32_t), hipMemcpyDeviceToHost, st));
   TTSX_HIP(hipMemcpyAsync(&bits, peak_bits, sizeof(unsigned), hipMemcpyDeviceToHost, st));
   TTSX_HIP(hipStreamSynchronize(st));
-  (void)hipFree(peak_bits);
   if (total_host) *total_host = total;
   if (peak_host) memcpy(peak_host, &bits, sizeof(float));
   return TTSX_OK;
