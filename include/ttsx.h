@@ -414,6 +414,16 @@ int ttsx_stft(const float* y, int B, int F, const ttsx_stft_params* sp, float* s
 int ttsx_istft(const float* spec_re, const float* spec_im, int B, int F, const ttsx_stft_params* sp,
                float* y, void* stream);
 
+/* ttsx_vocoder_griffin_lim without any device allocation (no counterpart in the reference).  For callers that
+ * cannot allocate: code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  Tables
+ * and the two padded signals live in a static device array of the library, so
+ *   B * round_up(n_fft + hop*(F-1), 4)  must not exceed 4 194 304 floats (e.g. 16 utterances of 900 frames);
+ * larger calls are rejected with TTSX_ERR_ARG.  The array (32 MiB) exists once per GPU for the life of the
+ * process and every call on that GPU uses it: calls that overlap on one GPU race (serialise them, or use
+ * handles).  Arguments and results as ttsx_vocoder_griffin_lim; does not synchronise. */
+int ttsx_griffin_lim_noalloc(const float* mag, const float* init_phase, const int32_t* n_frames, int B, int F,
+                             const ttsx_stft_params* sp, int iters, float preemph, float* wav, void* stream);
+
 /* ------------------------------------------------------------------ post-vocoder tail of a request
  * Replaces the per-sentence tail of Synthesizer.tts (Tacotron2/TTS/synthesizer.py:141-174):
  * trim_silence -> AudioProcessor.find_endpoint (Tacotron2/TTS/utils.py:944-951), concatenation with

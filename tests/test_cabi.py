@@ -89,6 +89,8 @@ def test_entry_points_reject_bad_arguments_before_any_device_call():
         "ttsx_t1_postnet_run": lambda: lib.ttsx_t1_postnet_run(None, one, None, 1, 8, one, None),
         "ttsx_spec_to_mag": lambda: lib.ttsx_spec_to_mag(None, None, 1, 8, 80, 1025, None, one, None),
         "ttsx_griffin_lim": lambda: lib.ttsx_griffin_lim(None, one, None, 1, 8, byref(sp), 60, 1.0, one, None),
+        "ttsx_griffin_lim_noalloc": lambda: lib.ttsx_griffin_lim_noalloc(None, one, None, 1, 8, byref(sp), 60, 1.0, one,
+                                                                         None),
         "ttsx_stft": lambda: lib.ttsx_stft(None, 1, 8, byref(sp), one, one, None),
         "ttsx_istft": lambda: lib.ttsx_istft(None, one, 1, 8, byref(sp), one, None),
         "ttsx_vocoder_create": lambda: lib.ttsx_vocoder_create(byref(sp), None, None),
@@ -113,6 +115,8 @@ def test_entry_points_reject_bad_arguments_before_any_device_call():
     assert "n_fft" in lib.ttsx_last_error_string().decode()
     assert lib.ttsx_stft(one, 1, 1, byref(sp), one, one, None) == _lib.ERR_ARG      # a single frame
     assert lib.ttsx_griffin_lim(one, one, None, 1, 8, byref(sp), -1, 1.0, one, None) == _lib.ERR_ARG
+    assert lib.ttsx_griffin_lim_noalloc(one, one, None, 64, 800, byref(sp), 60, 0.98, one, None) == _lib.ERR_ARG
+    assert "static scratch" in lib.ttsx_last_error_string().decode()               # beyond the fixed maximum
     assert lib.ttsx_postnet_run(one, one, None, 0, 8, one, None) == _lib.ERR_ARG    # empty batch
     assert lib.ttsx_encoder_convs_run(one, one, None, 1, 0, one, None) == _lib.ERR_ARG   # empty text
 

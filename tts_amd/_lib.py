@@ -122,6 +122,8 @@ PROTOTYPES = {
     "ttsx_spec_to_mag": (c_int, [_fp, _fp, c_int, c_int, c_int, c_int, POINTER(AudioParams), _fp, c_void_p]),
     "ttsx_griffin_lim": (c_int, [_fp, _fp, _fp, c_int, c_int, POINTER(StftParams), c_int, c_float, _fp,
                                  c_void_p]),
+    "ttsx_griffin_lim_noalloc": (c_int, [_fp, _fp, _fp, c_int, c_int, POINTER(StftParams), c_int, c_float, _fp,
+                                         c_void_p]),
     "ttsx_stft": (c_int, [_fp, c_int, c_int, POINTER(StftParams), _fp, _fp, c_void_p]),
     "ttsx_istft": (c_int, [_fp, _fp, c_int, c_int, POINTER(StftParams), _fp, c_void_p]),
     "ttsx_vocoder_create": (c_int, [POINTER(StftParams), c_void_p, POINTER(c_void_p)]),

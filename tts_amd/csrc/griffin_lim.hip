@@ -21,6 +21,7 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <mutex>
 #include <vector>
 
 #include "common.h"
@@ -1023,4 +1024,56 @@ extern "C" int ttsx_istft(const float* spec_re, const float* spec_im, int B, int
   if (rc) return rc;
   return with_temporary_vocoder(sp, stream,
                                 [&](ttsx_vocoder* v) { return ttsx_vocoder_istft(v, spec_re, spec_im, B, F, y, stream); });
+}
+
+// ------------------------------------------------------------------ allocation-free form
+// ttsx_vocoder_griffin_lim for callers that cannot allocate device memory (code under HIP graph capture, tight
+// serving loops, harnesses that forbid it).  Tables and both padded signals live in one file-scope device array:
+//   scratch = [ twiddles: 2048 floats | padded window: 2048 floats | signal 0 | signal 1 ]
+// with room for NOALLOC_MAX_PADDED floats per signal (B * (2048 + hop * (F - 1)), rounded up to 4 per
+// utterance): 4 Mi floats, e.g. 16 utterances of 900 frames.  The array costs 32 MiB + 16 KiB on every GPU
+// the library runs on, for the life of the process.  Every call on a GPU uses that GPU's copy: calls that
+// overlap on one GPU race.  Nothing has to start at zero: the tables are rebuilt by every call (a win_length may
+// differ from the last caller's) and each launch writes every padded position of its utterances before the next
+// one reads it.
+constexpr size_t NOALLOC_TABLE_FLOATS = 2 * MC + NFFT;
+constexpr size_t NOALLOC_MAX_PADDED = (size_t)1 << 22;
+static __device__ __align__(256) float scratch[NOALLOC_TABLE_FLOATS + 2 * NOALLOC_MAX_PADDED];
+
+namespace {
+constexpr int NOALLOC_MAX_DEVICES = 64;
+float* g_scratch_ptr[NOALLOC_MAX_DEVICES];  // device address of `scratch` on each GPU (the array's name is only a
+std::mutex g_scratch_mu;                    // host-side stand-in for it), found once per device
+}  // namespace
+
+extern "C" int ttsx_griffin_lim_noalloc(const float* mag, const float* init_phase, const int32_t* n_frames, int B,
+                                        int F, const ttsx_stft_params* sp, int iters, float preemph, float* wav,
+                                        void* stream) {
+  int rc = check_gl_args(mag, init_phase, wav, iters, preemph);
+  if (rc || (rc = check_stft_params(sp, B, F))) return rc;
+  const size_t n_pad = (size_t)B * make_geom(sp, F).LP;
+  TTSX_ARG(n_pad <= NOALLOC_MAX_PADDED,
+           "ttsx_griffin_lim_noalloc: B=%d x F=%d needs %zu floats per padded signal, the static scratch holds %zu "
+           "(use ttsx_vocoder_griffin_lim for larger batches)", B, F, n_pad, NOALLOC_MAX_PADDED);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  int dev = -1;
+  TTSX_HIP(hipGetDevice(&dev));
+  TTSX_ARG(dev >= 0 && dev < NOALLOC_MAX_DEVICES, "ttsx_griffin_lim_noalloc: device %d", dev);
+  float* base = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (!g_scratch_ptr[dev]) {
+      float* ptr = nullptr;
+      TTSX_HIP(hipGetSymbolAddress(reinterpret_cast<void**>(&ptr), HIP_SYMBOL(scratch)));
+      if ((rc = raise_deemph_lds())) return rc;
+      g_scratch_ptr[dev] = ptr;
+    }
+    base = g_scratch_ptr[dev];
+  }
+  float2* tw = reinterpret_cast<float2*>(base);
+  float* winpad = base + 2 * MC;
+  init_tables_kernel<<<NFFT / 256, 256, 0, st>>>(tw, winpad, sp->win_length);
+  TTSX_LAUNCH_CHECK();
+  float* const ybuf[2] = {base + NOALLOC_TABLE_FLOATS, base + NOALLOC_TABLE_FLOATS + n_pad};
+  return enqueue_griffin_lim(tw, winpad, ybuf, mag, init_phase, n_frames, B, F, sp, iters, preemph, wav, st);
 }
