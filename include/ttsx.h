@@ -144,6 +144,21 @@ int ttsx_t2_decoder_run(ttsx_t2_decoder* dec, const float* enc, const int32_t* e
                         int r, int max_steps, float stop_threshold, int fixed_steps, float* mel,
                         float* align, float* stop, int32_t* n_steps, int* steps_run_host, void* stream);
 
+/* The launch plan of the following runs (no reference counterpart).  By default the library picks, by batch
+ * size and text length, (a) one fused attention launch per step or three (query, energies, normalise + context),
+ * (b) whole LSTM launches or an early / late split along K whose early part rides along other launches, (c) at
+ * batch 1-2 without the fused kernel, whether the energies launch adds up the query shares itself.  All choices
+ * compute the same step (rounding differs at 1e-6).  Each argument: -1 by shape (default), 0 off, 1 on wherever
+ * the shapes allow.  For A/B timing and for tests that hold the alternatives against each other. */
+int ttsx_t2_decoder_set_plan(ttsx_t2_decoder* dec, int fused_attention, int split_lstm, int share_query);
+
+/* How a free run at batch 1-2 watches for its stop (no reference counterpart; the loop of models.py:651-668 asks
+ * the device after every step).  The host enqueues graphs of `chunk` decoder steps and keeps up to `ahead`
+ * steps outstanding while it polls a word the device writes into pinned host memory; at most ahead - 1 steps
+ * are enqueued past the stop frame.  Short chunks notice the stop sooner but cost more per step.  0 / 0 restores
+ * the defaults.  chunk: even, 2..32; ahead: chunk..128. */
+int ttsx_t2_decoder_set_polling(ttsx_t2_decoder* dec, int chunk, int ahead);
+
 /* Decoder steps the last ttsx_t2_decoder_run enqueued.  A free run notices the stop token of its last
  * utterance a few steps late (the loop of models.py:651-668 asks the device after every step; here the
  * host looks at a flag the device raises); the steps enqueued past it do no work that is kept.  No reference

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Run only the Tacotron2 decoder loop (for kernel profiles and step timing): dec_only.py B T steps.
+"""Run only the Tacotron2 decoder loop (for kernel profiles and step timing): dec_only.py B T steps [fused split share]
+(the optional launch-plan overrides of Tacotron2.set_plan: -1 by shape, 0 off, 1 on).
 Prints the marginal time per step (difference between a run of `steps` and one of `steps`/2 steps,
 so that per-run set-up cancels) and the all-in figure."""
 import os
@@ -13,7 +14,9 @@ import bench  # noqa: E402
 from tts_amd import synthetic  # noqa: E402
 
 B, T, S = (int(x) for x in sys.argv[1:4])
+plan = [int(x) for x in sys.argv[4:7]] + [-1] * (3 - len(sys.argv[4:7]))
 model, ap, sd = bench.build_model(0, 1)
+model.set_plan(*plan)
 ids = torch.as_tensor(synthetic.t2_text_ids(5, B, T)).cuda()
 enc = model.encode(ids)
 
@@ -31,6 +34,6 @@ def run(steps, reps=3):
 
 
 full, half = run(S), run(S // 2)
-print("B=%d T=%d split=%s: marginal %.2f us/step, all-in %.2f us/step (%d steps), fixed %.2f ms" %
-      (B, T, os.environ.get("TTSX_SPLIT", "auto"), (full - half) / (S - S // 2) * 1e6, full / S * 1e6, S,
+print("B=%d T=%d plan=%s: marginal %.2f us/step, all-in %.2f us/step (%d steps), fixed %.2f ms" %
+      (B, T, plan, (full - half) / (S - S // 2) * 1e6, full / S * 1e6, S,
        (2 * half - full) * 1e3))

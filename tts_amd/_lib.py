@@ -98,6 +98,8 @@ PROTOTYPES = {
     "ttsx_t2_decoder_run": (c_int, [c_void_p, _fp, _fp, c_int, c_int, c_int, c_int, c_float, c_int, _fp, _fp,
                                     _fp, _fp, POINTER(c_int), c_void_p]),
     "ttsx_t2_decoder_steps_launched": (c_int, [c_void_p]),
+    "ttsx_t2_decoder_set_plan": (c_int, [c_void_p, c_int, c_int, c_int]),
+    "ttsx_t2_decoder_set_polling": (c_int, [c_void_p, c_int, c_int]),
     "ttsx_t2_decoder_begin": (c_int, [c_void_p, _fp, _fp, c_int, c_int, c_void_p]),
     "ttsx_t2_decoder_load_state": (c_int, [c_void_p] + [_fp] * 7 + [c_void_p]),
     "ttsx_t2_decoder_step": (c_int, [c_void_p, _fp, c_int, _fp, _fp, _fp, c_void_p]),

@@ -71,6 +71,10 @@ struct RunCtx {
   float* align;      // [B, align_rows, T]
   float* stop;       // [B, stop_rows]
   int32_t* n_steps;  // [B]
+  // words in pinned host memory that the device writes and the host polls while it keeps enqueueing chunks (no
+  // stream synchronisation, no copy): [0] every utterance has ended, [1] steps completed (written by the last
+  // node of every chunk).  Null: not reported.
+  int* host_words;
 };
 
 // A step's launches do their arithmetic but keep nothing once every utterance has ended.  The test compares the
@@ -350,7 +354,10 @@ __device__ __forceinline__ float epilogue_quad(const GemmP& p, int quad, int b, 
         if (s > cx->threshold && cx->n_steps[b] == 0) {
           cx->n_steps[b] = cx->base + p.step_in_chunk + 1;  // steps run so far, the stop frame included
           const int done = atomicAdd(&cx->n_done, 1) + 1;
-          if (cx->free_running && done == cx->B) cx->done_at = cx->base + p.step_in_chunk, cx->all_done = 1;
+          if (cx->free_running && done == cx->B) {
+            cx->done_at = cx->base + p.step_in_chunk, cx->all_done = 1;
+            if (cx->host_words) __hip_atomic_store(cx->host_words, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          }
         }
       }
     } else {
@@ -400,10 +407,9 @@ struct GemmOp {
     const int kbase = kpart * (KGW * GEMM_WAVES);
     const int rb = p.rb0 + (wg % ngrp) * R, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int b0 = (wg / ngrp) * (NT * 16);
-#ifndef TTSX_DMAX_BIG
-#define TTSX_DMAX_BIG 4
-#endif
-    constexpr int DMAX = (R * NT >= 4) ? TTSX_DMAX_BIG : (NT == 1 && R == 1 ? 8 : 6);
+    // k-groups in flight per wave (deeper prefetch on the big tiles measured slower: 54.0 / 56.4 / 57.2 us per
+    // step at 6 / 8 / 10 against 53.4 at 4)
+    constexpr int DMAX = (R * NT >= 4) ? 4 : (NT == 1 && R == 1 ? 8 : 6);
     constexpr int D = KGW < DMAX ? KGW : DMAX;
     constexpr int TILES = R * NT, TPW = (TILES + GEMM_WAVES - 1) / GEMM_WAVES;
     f32x4(*red)[TILES][64];
@@ -1209,6 +1215,16 @@ struct FusedAttnOp {
     }
     const float vw = p.v_w[tid & (ATT_DIM - 1)];
     const float vb = p.v_b[0];
+    // processed inputs of the wave's first position tile: requested with the early group where the registers allow
+    // (not in the two-workgroups-per-CU variant), so that the energies start without a memory round trip of their own
+    constexpr bool P_EARLY = PRE == 0;
+    float4 pv0[P_EARLY ? 8 : 1];
+    if (P_EARLY) {
+      const int t = 16 * wave + (lane & 15);
+      const float* Prow = p.P + ((size_t)b * T + (t < T ? t : 0)) * ATT_DIM + 4 * (lane >> 4);
+#pragma unroll
+      for (int dt = 0; dt < 8; ++dt) pv0[dt] = *reinterpret_cast<const float4*>(Prow + 16 * dt);
+    }
     // ---- stage the early group
     {
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1266,7 +1282,10 @@ struct FusedAttnOp {
       const float* Prow = p.P + ((size_t)b * T + (t < T ? t : 0)) * ATT_DIM + 4 * lq;
       float4 pv[8];
 #pragma unroll
-      for (int dt = 0; dt < 8; ++dt) pv[dt] = *reinterpret_cast<const float4*>(Prow + 16 * dt);
+      for (int dt = 0; dt < 8; ++dt) {
+        if (P_EARLY && i == 0) pv[dt] = pv0[dt];
+        else pv[dt] = *reinterpret_cast<const float4*>(Prow + 16 * dt);
+      }
       f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int kk = 0; kk < 16; ++kk) {
@@ -1450,6 +1469,7 @@ __global__ void pack_attn_frag_kernel(float* __restrict__ wlc_p, float* __restri
 // (unconditional: steps enqueued after the last stop must keep counting, or step_done() would take them for live)
 __global__ void ctx_advance_kernel(RunCtx* c, int n) {
   c->base += n;
+  if (c->host_words) __hip_atomic_store(c->host_words + 1, c->base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   c->out_base += n;
 }
 __global__ void finalize_steps_kernel(int32_t* n_steps, int B, int steps_launched) {
@@ -1541,16 +1561,30 @@ struct ttsx_t2_decoder {
   int steps_done;    // host mirror of rc.base
   int last_launched; // decoder steps the last run() enqueued (>= the steps any utterance needed)
   bool begun;
-  // cached chunk graph
-  hipGraphExec_t graph;
+  // cached chunk graphs: slot 0 for the long chunk (fixed-step runs, batches), slot 1 for the short chunk of a
+  // free-running decode at batch 1-2
+  struct ChunkGraph {
+    hipGraphExec_t exec;
+    int B, T, r, gen, chunk, split, fused;
+  } graphs[2];
   hipStream_t cap_stream;  // capture-only stream: the caller's stream may be the legacy default stream
-  int g_B, g_T, g_r, g_gen, g_chunk, g_split, g_fused;
+  int* host_words_dev;     // device-side address of host_flag (mapped pinned memory)
+  int poll_chunk, poll_ahead;  // free run at batch 1-2: steps per graph and steps kept in flight (0: defaults)
+  int plan_fused, plan_split, plan_share_q;  // ttsx_t2_decoder_set_plan: -1 by shape (default), 0 off, 1 on
   bool share_q;  // three-launch attention without the query launch: the energies op adds up the query shares
 };
 
 namespace {
 
-constexpr int CHUNK = 32;
+// Steps per cached graph.  A free run notices its last stop through a word the device writes into pinned host
+// memory (no stream synchronisation, no copy).  At batch 1-2 every step enqueued past the stop frame is pure
+// latency, so the host enqueues short graphs, one at a time (the next one when the device reports the previous
+// one complete): fewer than CHUNK_SHORT steps go past the stop.  Measured on a 308-step utterance (decoder time /
+// steps enqueued): 4 steps x 2 in flight 10.55 ms / 312, 8 x 1 10.42 / 312, 16 x 1 10.28 / 320, 32 x 1 10.14 / 320,
+// 32 x 2 10.96 / 352 - a short graph costs ~0.5 us more per step (31.7 us per step at 32, 33.4 at 8), about what
+// the smaller overshoot gives back; larger batches use the long chunk.  (Both even: the h ping-pong parity of a
+// chunk's steps is fixed at capture.)
+constexpr int CHUNK = 32, CHUNK_SHORT = 8;
 int gemm_shape(int Bpad, int nrb);
 int query_groups(int B, int Bpad);
 hipError_t set_fused_lds();
@@ -1586,8 +1620,10 @@ int pack_layer(float** wp, float** bp, const float* w1, int k1, const float* w2,
 }
 
 void drop_graph(ttsx_t2_decoder* d) {
-  if (d->graph) (void)hipGraphExecDestroy(d->graph);
-  d->graph = nullptr;
+  for (auto& g : d->graphs) {
+    if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    g.exec = nullptr;
+  }
 }
 
 // Buffers sized by the (padded) batch alone - they hold the recurrent state, which
@@ -1617,7 +1653,10 @@ void free_workspace(ttsx_t2_decoder* d) {
   d->cap_B = 0;
 }
 
-int proj_rows(const ttsx_t2_decoder* d) { return d->odim + 16 + PRENET_DIM; }
+// Rows of the projection launch for reduction factor r: the 80 r mel rows a step keeps, 16 rows for the composed
+// stop logit (one used) and the 256 composed prenet rows.  The remaining 80 (r_init - r) rows of linear_projection
+// feed nothing but the stopnet, whose logit is already one composed row: they are never multiplied.
+int proj_rows(int r) { return MEL_DIM * r + 16 + PRENET_DIM; }
 
 int ensure_workspace(ttsx_t2_decoder* d, int B, int T) {
   // column padding: 16 / 32 / multiples of 64 (a count of 3 column tiles would leave the LSTM launches
@@ -1639,7 +1678,7 @@ int ensure_workspace(ttsx_t2_decoder* d, int B, int T) {
     rc |= dev_alloc(&d->g_a, 2 * 4 * QUERY_DIM * cb);  // two K parts
     rc |= dev_alloc(&d->g_d, 2 * 4 * DEC_DIM * cb);
     rc |= dev_alloc(&d->q, ATT_DIM * cb);
-    rc |= dev_alloc(&d->o, (size_t)round_up(proj_rows(d), 16) * cb);
+    rc |= dev_alloc(&d->o, (size_t)round_up(proj_rows(d->r_init), 16) * cb);
     rc |= dev_alloc(&d->len_ws, cb);
     rc |= dev_alloc(&d->u_fa, cb);
     rc |= dev_alloc(&d->win_idx, cb);
@@ -1677,13 +1716,13 @@ int ensure_proj(ttsx_t2_decoder* d, int r, hipStream_t st) {
   compose_proj_ext_kernel<<<ext_rows, 256, 0, st>>>(ext_w, ext_b, d->proj_w_src, d->proj_b_src, d->stop_w_src,
                                                    d->stop_b_src, d->a1f, d->b1f, d->odim, r);
   TTSX_LAUNCH_CHECK();
-  const int rows = proj_rows(d);
+  const int rows = proj_rows(r), kept = MEL_DIM * r;
   if (dev_alloc(&all_w, (size_t)rows * K) || dev_alloc(&all_b, rows)) return TTSX_ERR_HIP;
-  TTSX_HIP(hipMemcpyAsync(all_w, d->proj_w_src, sizeof(float) * (size_t)d->odim * K, hipMemcpyDeviceToDevice, st));
-  TTSX_HIP(hipMemcpyAsync(all_w + (size_t)d->odim * K, ext_w, sizeof(float) * (size_t)ext_rows * K,
+  TTSX_HIP(hipMemcpyAsync(all_w, d->proj_w_src, sizeof(float) * (size_t)kept * K, hipMemcpyDeviceToDevice, st));
+  TTSX_HIP(hipMemcpyAsync(all_w + (size_t)kept * K, ext_w, sizeof(float) * (size_t)ext_rows * K,
                           hipMemcpyDeviceToDevice, st));
-  TTSX_HIP(hipMemcpyAsync(all_b, d->proj_b_src, sizeof(float) * d->odim, hipMemcpyDeviceToDevice, st));
-  TTSX_HIP(hipMemcpyAsync(all_b + d->odim, ext_b, sizeof(float) * ext_rows, hipMemcpyDeviceToDevice, st));
+  TTSX_HIP(hipMemcpyAsync(all_b, d->proj_b_src, sizeof(float) * kept, hipMemcpyDeviceToDevice, st));
+  TTSX_HIP(hipMemcpyAsync(all_b + kept, ext_b, sizeof(float) * ext_rows, hipMemcpyDeviceToDevice, st));
   int rc = pack_layer(&d->w_proj, &d->b_proj, all_w, K, nullptr, 0, all_b, nullptr, rows, 0, st);
   TTSX_HIP(hipStreamSynchronize(st));
   (void)hipFree(ext_w), (void)hipFree(ext_b), (void)hipFree(all_w), (void)hipFree(all_b);
@@ -1772,8 +1811,6 @@ int gemm_shape(int Bpad, int nrb) {
   if (nrb % 2 == 0 && nrb / 2 * nt_total >= cus) shape = 21;
   if (nrb % 2 == 0 && nt_total % 2 == 0 && nrb / 2 * (nt_total / 2) >= cus) shape = 22;
   if (nrb % 4 == 0 && nt_total % 2 == 0 && nrb / 4 * (nt_total / 2) >= cus) shape = 42;
-  if (const char* e = getenv("TTSX_GEMM_SHAPE")) shape = atoi(e);  // tuning override
-  if (shape != 21 && shape != 22 && shape != 42 && shape != 24) shape = 11;
   return shape;
 }
 // unit groups of the attention LSTM launch (= workgroups along the row axis): one share of the query each
@@ -2036,10 +2073,10 @@ int enqueue_step(ttsx_t2_decoder* d, int i, bool first, bool more, hipStream_t s
   g.gates = nullptr;
   g.seg[0] = Seg{{d->h_d[0], d->h_d[1]}, 2, DEC_DIM / 16};
   g.seg[1] = Seg{{d->ctx, nullptr}, 0, ENC_DIM / 16};
-  g.out[0] = d->o, g.out[1] = nullptr, g.c = nullptr, g.x1 = d->x1, g.o_quads = d->odim / 4;
+  g.out[0] = d->o, g.out[1] = nullptr, g.c = nullptr, g.x1 = d->x1, g.o_quads = MEL_DIM * d->proj_r / 4;
   pc = mfma ? k_piece(pa_next, 0) : pa_next.piece(1);
   pc.on = split && more;
-  return launch_gemm<MODE_PROJ, 12, PK1>(d, g, ceil_div(proj_rows(d), 16), false, &pc, st);
+  return launch_gemm<MODE_PROJ, 12, PK1>(d, g, ceil_div(proj_rows(d->proj_r), 16), false, &pc, st);
 }
 
 int push_ctx(ttsx_t2_decoder* d, hipStream_t st) {
@@ -2049,32 +2086,34 @@ int push_ctx(ttsx_t2_decoder* d, hipStream_t st) {
   return TTSX_OK;
 }
 
-// Launch `n` steps as one graph (captured once per (B, T, r, workspace) and chunk size).
-int launch_chunk(ttsx_t2_decoder* d, int n, hipStream_t st) {
-  const bool cached = d->graph && d->g_B == d->B && d->g_T == d->T && d->g_r == d->rc_host->r &&
-                      d->g_gen == d->ws_gen && d->g_chunk == n && d->g_split == (int)d->split + 2 * (int)d->share_q &&
-                      d->g_fused == (int)d->fused;
-  if (!cached && n == CHUNK) {
-    drop_graph(d);
-    hipGraph_t graph = nullptr;
-    hipStream_t cs = d->cap_stream;
-    TTSX_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
-    int rc = TTSX_OK;
-    for (int i = 0; i < n && !rc; ++i) rc = enqueue_step(d, i, i == 0, i + 1 < n, cs);
-    if (!rc) ctx_advance_kernel<<<1, 1, 0, cs>>>(d->rc, n);
-    hipError_t e = hipStreamEndCapture(cs, &graph);
-    if (rc) {
-      if (graph) (void)hipGraphDestroy(graph);
-      return rc;
+// Launch `n` steps; a full chunk (n == chunk, CHUNK or CHUNK_SHORT) goes as one graph, captured once per
+// (B, T, r, workspace, launch plan) and chunk size.
+int launch_chunk(ttsx_t2_decoder* d, int n, int chunk, hipStream_t st) {
+  if (n == chunk) {
+    ttsx_t2_decoder::ChunkGraph& g = d->graphs[chunk == CHUNK ? 0 : 1];   // (the cache key includes the chunk size)
+    const int split = (int)d->split + 2 * (int)d->share_q;
+    const bool cached = g.exec && g.B == d->B && g.T == d->T && g.r == d->rc_host->r && g.gen == d->ws_gen &&
+                        g.chunk == n && g.split == split && g.fused == (int)d->fused;
+    if (!cached) {
+      if (g.exec) (void)hipGraphExecDestroy(g.exec);
+      g.exec = nullptr;
+      hipGraph_t graph = nullptr;
+      hipStream_t cs = d->cap_stream;
+      TTSX_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
+      int rc = TTSX_OK;
+      for (int i = 0; i < n && !rc; ++i) rc = enqueue_step(d, i, i == 0, i + 1 < n, cs);
+      if (!rc) ctx_advance_kernel<<<1, 1, 0, cs>>>(d->rc, n);
+      hipError_t e = hipStreamEndCapture(cs, &graph);
+      if (rc) {
+        if (graph) (void)hipGraphDestroy(graph);
+        return rc;
+      }
+      TTSX_HIP(e);
+      TTSX_HIP(hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0));
+      (void)hipGraphDestroy(graph);
+      g.B = d->B, g.T = d->T, g.r = d->rc_host->r, g.gen = d->ws_gen, g.chunk = n, g.split = split, g.fused = d->fused;
     }
-    TTSX_HIP(e);
-    TTSX_HIP(hipGraphInstantiate(&d->graph, graph, nullptr, nullptr, 0));
-    (void)hipGraphDestroy(graph);
-    d->g_B = d->B, d->g_T = d->T, d->g_r = d->rc_host->r, d->g_gen = d->ws_gen, d->g_chunk = n;
-    d->g_split = (int)d->split + 2 * (int)d->share_q, d->g_fused = d->fused;
-  }
-  if (n == CHUNK) {
-    TTSX_HIP(hipGraphLaunch(d->graph, st));
+    TTSX_HIP(hipGraphLaunch(g.exec, st));
     return TTSX_OK;
   }
   for (int i = 0; i < n; ++i) {
@@ -2084,6 +2123,24 @@ int launch_chunk(ttsx_t2_decoder* d, int n, hipStream_t st) {
   ctx_advance_kernel<<<1, 1, 0, st>>>(d->rc, n);
   TTSX_LAUNCH_CHECK();
   return TTSX_OK;
+}
+
+// Busy-wait until the device has reported `want` completed steps or the end of every utterance in the pinned
+// words.  The stream is queried now and then: a failed stream ends the wait with an error, a drained one with
+// whatever the words hold.
+int wait_progress(const volatile int* words, int want, hipStream_t st) {
+  for (long spin = 0;; ++spin) {
+    if (words[0] || words[1] >= want) return TTSX_OK;
+    if ((spin & 0xfff) == 0xfff) {
+      const hipError_t q = hipStreamQuery(st);
+      if (q == hipSuccess) return TTSX_OK;
+      if (q != hipErrorNotReady) {
+        ttsx_set_error("decoder stream failed while waiting for the stop flag: %s", hipGetErrorString(q));
+        return TTSX_ERR_HIP;
+      }
+    }
+    __builtin_ia32_pause();
+  }
 }
 
 }  // namespace
@@ -2101,6 +2158,7 @@ extern "C" int ttsx_t2_decoder_create(const ttsx_t2_decoder_weights* w, int r_in
   ScopeExit on_fail([&] { (void)ttsx_t2_decoder_destroy(d); });
   ScopeExit free_tmp([&] { (void)hipFree(w_ih2), (void)hipFree(a2f), (void)hipFree(b2f); });
   d->r_init = r_init, d->norm = attn_norm, d->odim = MEL_DIM * r_init;
+  d->plan_fused = d->plan_split = d->plan_share_q = -1;
   int rc = 0;
   rc |= pack_layer(&d->w_lstm1, &d->b_lstm1, w->attn_rnn_w_ih, PRENET_DIM + ENC_DIM, w->attn_rnn_w_hh, QUERY_DIM,
                    w->attn_rnn_b_ih, w->attn_rnn_b_hh, 4 * QUERY_DIM, QUERY_DIM, st);
@@ -2160,7 +2218,9 @@ extern "C" int ttsx_t2_decoder_create(const ttsx_t2_decoder_weights* w, int r_in
   TTSX_HIP(hipMalloc(reinterpret_cast<void**>(&d->rc), sizeof(RunCtx)));
   TTSX_HIP(hipMemsetAsync(d->rc, 0, sizeof(RunCtx), st));
   TTSX_HIP(hipHostMalloc(reinterpret_cast<void**>(&d->rc_host), sizeof(RunCtx), hipHostMallocDefault));
-  TTSX_HIP(hipHostMalloc(reinterpret_cast<void**>(&d->host_flag), 4 * sizeof(int), hipHostMallocDefault));
+  TTSX_HIP(hipHostMalloc(reinterpret_cast<void**>(&d->host_flag), 4 * sizeof(int), hipHostMallocMapped));
+  TTSX_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&d->host_words_dev), d->host_flag, 0));
+  memset(d->host_flag, 0, 4 * sizeof(int));
   memset(d->rc_host, 0, sizeof(RunCtx));
   TTSX_HIP(hipStreamCreateWithFlags(&d->cap_stream, hipStreamNonBlocking));
   TTSX_HIP(hipStreamSynchronize(st));
@@ -2223,7 +2283,6 @@ extern "C" int ttsx_t2_decoder_set_attention(ttsx_t2_decoder* d, const ttsx_t2_a
   if (rc) return TTSX_ERR_HIP;
   TTSX_HIP(hipStreamSynchronize(st));
   drop_graph(d);
-  d->g_gen = -1;
   return TTSX_OK;
 }
 
@@ -2270,30 +2329,28 @@ extern "C" int ttsx_t2_decoder_begin(ttsx_t2_decoder* d, const float* enc, const
            "ttsx_t2_decoder_begin: encoder length %d exceeds the LDS budget of the attention variants", T);
   d->B = B, d->T = T;
   {
-    // early/late LSTM split: always in the GEMV regime, where every launch is latency-bound (rule for the MFMA
-    // engine below); TTSX_SPLIT=0 turns it off
-    const char* e = getenv("TTSX_SPLIT");
-    // One-workgroup-per-utterance attention (TTSX_FUSED_ATTN=0: always the three-launch path; =1: the fused
-    // kernel wherever its shapes allow).  One workgroup walks all positions of its utterance through ONE CU's
+    // The launch plan of a run, by shape; ttsx_t2_decoder_set_plan overrides each choice (A/B timing, and the
+    // parity tests that hold the alternatives against each other).
+    // Early/late LSTM split: always in the GEMV regime, where every launch is latency-bound (rule for the MFMA
+    // engine below).
+    // One-workgroup-per-utterance attention: one workgroup walks all positions of its utterance through ONE CU's
     // vector memory pipe (~2 KB per position), so it pays up to a length that depends on how much of the chip the
     // batch fills.  Measured per step, fused / three launches:
     //   B=1:  T=64 30.6 / 33.0 us, T=128 32.5 / 33.7, T=250 39.9 / 33.5      -> up to 128 positions at batch 1-2
     //   B=16: T=128 37.9 / 40.7, T=512 59 / 49;  B=64: T=128 51.3 / 54.5, T=256 58.3 / 62.9, T=512 72 / 79;
     //   B=128: T=128 79.4 / 87.0                                              -> 256, and 512 from batch 48 on
-    const char* f = getenv("TTSX_FUSED_ATTN");
-    const int t_max = B >= 48 ? FA_TMAX : (B > GEMV_MAX_B || (f && f[0] == '1')) ? 256 : 128;
-    d->fused = T <= t_max && !d->variant && !graves && !(f && f[0] == '0');
+    const int t_max = B >= 48 ? FA_TMAX : (B > GEMV_MAX_B || d->plan_fused == 1) ? 256 : 128;
+    d->fused = T <= t_max && !d->variant && !graves && d->plan_fused != 0;
     // Batch 1-2 without the fused kernel: the query launch is dropped and the energies workgroups add up the
-    // query shares themselves (TTSX_SHARE_Q=0: keep the query launch).
-    const char* sq = getenv("TTSX_SHARE_Q");
-    d->share_q = B <= GEMV_MAX_B && !d->fused && !d->variant && !graves && !(sq && sq[0] == '0');
+    // query shares themselves.
+    d->share_q = B <= GEMV_MAX_B && !d->fused && !d->variant && !graves && d->plan_share_q != 0;
     // On the MFMA engine the split needs the fused attention launch (one CU per utterance busy for ~11 us: the
     // shadow the early decoder-LSTM columns run in; the three-launch attention fills the chip itself), and it
     // pays while the pieces fit into that shadow.  Measured per step, split / whole LSTM launches (T=128 unless
     // noted): B=4 34.1 / 37.2 us, B=16 33.7 / 37.4, B=32 38.2 / 41.0, B=32 T=256 45.2 / 48.8, B=64 T=64 48.1 / 47.6,
-    // B=64 48.1 / 49.1, B=64 T=200 50.4 / 56.7, B=96 75.0 / 73.6.  TTSX_SPLIT=1 forces it wherever it is possible.
-    const bool pays = d->Bpad <= 32 || (d->Bpad == 64 && T > 64) || (e && e[0] == '1');
-    d->split = (B <= GEMV_MAX_B || (d->fused && pays)) && !(e && e[0] == '0') && !d->variant && !graves;
+    // B=64 48.1 / 49.1, B=64 T=200 50.4 / 56.7, B=96 75.0 / 73.6.
+    const bool pays = d->Bpad <= 32 || (d->Bpad == 64 && T > 64) || d->plan_split == 1;
+    d->split = (B <= GEMV_MAX_B || (d->fused && pays)) && d->plan_split != 0 && !d->variant && !graves;
   }
   d->parity0 = 0;
   const size_t cb = d->Bpad;
@@ -2315,7 +2372,7 @@ extern "C" int ttsx_t2_decoder_begin(ttsx_t2_decoder* d, const float* enc, const
     TTSX_HIP(hipMemsetAsync(d->c_d, 0, sizeof(float) * DEC_DIM * cb, st));
   }
   TTSX_HIP(hipMemsetAsync(d->q, 0, sizeof(float) * ATT_DIM * cb, st));
-  TTSX_HIP(hipMemsetAsync(d->o, 0, sizeof(float) * (size_t)round_up(proj_rows(d), 16) * cb, st));
+  TTSX_HIP(hipMemsetAsync(d->o, 0, sizeof(float) * (size_t)round_up(proj_rows(d->r_init), 16) * cb, st));
   TTSX_HIP(hipMemsetAsync(d->n1, 0, sizeof(float) * QUERY_DIM * cb, st));
   TTSX_HIP(hipMemsetAsync(d->gbk, 0, sizeof(float) * (size_t)round_up(3 * GRAVES_MAX_K, 16) * cb, st));
   TTSX_HIP(hipMemsetAsync(d->a_prev, 0, sizeof(float) * (size_t)B * T, st));
@@ -2410,7 +2467,7 @@ extern "C" int ttsx_t2_decoder_step(ttsx_t2_decoder* d, const float* memory, int
   if (rc) return rc;
   RunCtx* h = d->rc_host;
   h->base = d->steps_done, h->out_base = 0, h->all_done = 0, h->done_at = NEVER_DONE, h->n_done = 0;
-  h->r = r, h->free_running = 0, h->threshold = 2.f;
+  h->r = r, h->free_running = 0, h->threshold = 2.f, h->host_words = nullptr;
   h->mel = frames, h->mel_rows = r, h->align = align, h->align_rows = 1, h->stop = stop, h->stop_rows = 1;
   // n_steps bookkeeping is not wanted here: point it at the energies scratch, never read back
   h->n_steps = reinterpret_cast<int32_t*>(d->energies);
@@ -2443,19 +2500,38 @@ extern "C" int ttsx_t2_decoder_run(ttsx_t2_decoder* d, const float* enc, const i
   h->r = r, h->free_running = fixed_steps ? 0 : 1, h->threshold = stop_threshold;
   h->mel = mel, h->mel_rows = max_steps * r, h->align = align, h->align_rows = max_steps;
   h->stop = stop, h->stop_rows = max_steps, h->n_steps = n_steps;
+  h->host_words = fixed_steps ? nullptr : d->host_words_dev;
+  d->host_flag[0] = 0, d->host_flag[1] = 0;
   rc = push_ctx(d, st);
   if (rc) return rc;
   int launched = 0;
-  d->host_flag[0] = 0;
-  while (launched < max_steps) {
-    const int n = std::min(CHUNK, max_steps - launched);
-    rc = launch_chunk(d, n, st);
-    if (rc) return rc;
-    launched += n;
-    if (!fixed_steps) {
-      TTSX_HIP(hipMemcpyAsync(d->host_flag, &d->rc->all_done, sizeof(int), hipMemcpyDeviceToHost, st));
-      TTSX_HIP(hipStreamSynchronize(st));
-      if (d->host_flag[0]) break;
+  if (fixed_steps) {
+    while (launched < max_steps) {
+      const int n = std::min(CHUNK, max_steps - launched);
+      if ((rc = launch_chunk(d, n, CHUNK, st))) return rc;
+      launched += n;
+    }
+  } else {
+    // chunks in flight: two short ones at batch 1-2, one long one otherwise
+    int chunk = CHUNK, ahead = CHUNK;
+    if (B <= GEMV_MAX_B) {
+      chunk = d->poll_chunk ? d->poll_chunk : CHUNK_SHORT;
+      ahead = d->poll_ahead ? d->poll_ahead : chunk;
+    }
+    const volatile int* words = d->host_flag;
+    while (launched < max_steps && !words[0]) {
+      // enqueue while fewer than `ahead` steps are outstanding, else wait for the device to report progress
+      if (launched - words[1] >= ahead) {
+        if ((rc = wait_progress(words, launched - ahead + 1, st))) return rc;
+        if (!words[0] && launched - words[1] >= ahead) {   // the stream drained without reporting
+          ttsx_set_error("ttsx_t2_decoder_run: the device reported no progress for the enqueued steps");
+          return TTSX_ERR_STATE;
+        }
+        continue;
+      }
+      const int n = std::min(chunk, max_steps - launched);
+      if ((rc = launch_chunk(d, n, chunk, st))) return rc;
+      launched += n;
     }
   }
   finalize_steps_kernel<<<ceil_div(B, 256), 256, 0, st>>>(n_steps, B, launched);
@@ -2470,6 +2546,24 @@ extern "C" int ttsx_t2_decoder_run(ttsx_t2_decoder* d, const float* enc, const i
   d->last_launched = launched;
   d->steps_done = run;
   d->begun = false;  // the state belongs to a finished batch
+  return TTSX_OK;
+}
+
+extern "C" int ttsx_t2_decoder_set_plan(ttsx_t2_decoder* d, int fused_attention, int split_lstm, int share_query) {
+  TTSX_ARG(d, "ttsx_t2_decoder_set_plan: null handle");
+  for (int v : {fused_attention, split_lstm, share_query})
+    TTSX_ARG(v >= -1 && v <= 1, "ttsx_t2_decoder_set_plan: %d is not -1 (by shape), 0 (off) or 1 (on)", v);
+  d->plan_fused = fused_attention, d->plan_split = split_lstm, d->plan_share_q = share_query;
+  return TTSX_OK;
+}
+
+extern "C" int ttsx_t2_decoder_set_polling(ttsx_t2_decoder* d, int chunk, int ahead) {
+  TTSX_ARG(d, "ttsx_t2_decoder_set_polling: null handle");
+  TTSX_ARG(chunk == 0 || (chunk >= 2 && chunk <= CHUNK && chunk % 2 == 0),
+           "ttsx_t2_decoder_set_polling: chunk=%d must be 0 or an even number in 2..%d", chunk, CHUNK);
+  TTSX_ARG(ahead == 0 || (chunk > 0 && ahead >= chunk && ahead <= 4 * CHUNK),
+           "ttsx_t2_decoder_set_polling: ahead=%d must be 0 or in chunk..%d", ahead, 4 * CHUNK);
+  d->poll_chunk = chunk, d->poll_ahead = ahead;
   return TTSX_OK;
 }
 
@@ -2811,7 +2905,10 @@ struct T1StopOp {
           cx->n_steps[b] = tn;
           // this op rides along the first launch of step idx + 1, whose other workgroups are already running:
           // that step completes (its output rows are masked), the ones after it keep nothing
-          if (atomicAdd(&cx->n_done, 1) + 1 == cx->B) cx->done_at = cx->base + p.idx + 1, cx->all_done = 1;
+          if (atomicAdd(&cx->n_done, 1) + 1 == cx->B) {
+            cx->done_at = cx->base + p.idx + 1, cx->all_done = 1;
+            if (cx->host_words) __hip_atomic_store(cx->host_words, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          }
         }
       }
     }

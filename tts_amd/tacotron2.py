@@ -323,6 +323,11 @@ class Tacotron2:
         s = steps_run.value
         return mel[:, :s * r], align[:, :s], stop[:, :s], n_steps, s
 
+    def set_plan(self, fused_attention=-1, split_lstm=-1, share_query=-1):
+        """Override the decoder's launch plan (ttsx_t2_decoder_set_plan): -1 by shape, 0 off, 1 on."""
+        _lib.check(_lib.load().ttsx_t2_decoder_set_plan(self._dec_handle, int(fused_attention), int(split_lstm),
+                                                        int(share_query)), "ttsx_t2_decoder_set_plan")
+
     def last_steps_launched(self):
         """Decoder steps the last decode() enqueued (at least the steps any utterance needed)."""
         return int(_lib.load().ttsx_t2_decoder_steps_launched(self._dec_handle))
