@@ -352,10 +352,16 @@ int ttsx_t1_encoder_run(ttsx_t1* m, const float* emb, const int32_t* lengths, in
  * lengths [B] int32 or NULL as above: attention runs over the first lengths[b] positions and the
  * stop rule uses that length; align columns beyond it are zero.  Rows of mel / align / stop past
  * n_steps[b] are not written.  T <= 512.  Synchronises `stream`.
- * Runs as seven launches per step over the whole chip (a hipGraph per 32 steps); the environment
- * variable TTSX_T1_PERSISTENT=1 selects the one-workgroup-per-utterance kernel instead. */
+ * At batch 1-2 with T <= 128 the whole loop is one persistent launch of a 33-workgroup team per utterance that
+ * keeps every decoder weight in registers / LDS; otherwise seven launches per step over the whole chip (a hipGraph
+ * per 32 steps).  ttsx_t1_set_plan overrides the choice. */
 int ttsx_t1_decoder_run(ttsx_t1* m, const float* enc, const int32_t* lengths, int B, int T, int max_decoder_steps,
                         float* mel, float* align, float* stop, int32_t* n_steps, int* steps_run_host, void* stream);
+/* Decoder form of the following runs (no reference counterpart): -1 by shape (default), 0 the launch chain,
+ * 1 the on-chip team kernel where the shapes allow (B <= 2, T <= 128, memory queue of 400 floats, r = 2), 2 the
+ * single-workgroup-per-utterance kernel.  All compute the same steps (rounding differs at 1e-6). */
+int ttsx_t1_set_plan(ttsx_t1* m, int decoder);
+
 /* mel [B,F,80] -> linear [B,F,linear_dim] = sigmoid(last_linear(PostCBHG(mel))) (:698-699).
  * n_frames [B] int32 valid frames per utterance or NULL (= F); rows past it are unspecified. */
 int ttsx_t1_postnet_run(ttsx_t1* m, const float* mel, const int32_t* n_frames, int B, int F, float* linear,

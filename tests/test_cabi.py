@@ -88,6 +88,7 @@ def test_entry_points_reject_bad_arguments_before_any_device_call():
         "ttsx_t1_encoder_run": lambda: lib.ttsx_t1_encoder_run(None, one, None, 1, 8, one, None),
         "ttsx_t1_decoder_run": lambda: lib.ttsx_t1_decoder_run(None, one, None, 1, 8, 10, one, one, one, one, byref(n),
                                                                None),
+        "ttsx_t1_set_plan": lambda: lib.ttsx_t1_set_plan(None, -1),
         "ttsx_t1_postnet_run": lambda: lib.ttsx_t1_postnet_run(None, one, None, 1, 8, one, None),
         "ttsx_spec_to_mag": lambda: lib.ttsx_spec_to_mag(None, None, 1, 8, 80, 1025, None, one, None),
         "ttsx_griffin_lim": lambda: lib.ttsx_griffin_lim(None, one, None, 1, 8, byref(sp), 60, 1.0, one, None),

@@ -120,6 +120,7 @@ PROTOTYPES = {
     "ttsx_t1_encoder_run": (c_int, [c_void_p, _fp, _fp, c_int, c_int, _fp, c_void_p]),
     "ttsx_t1_decoder_run": (c_int, [c_void_p, _fp, _fp, c_int, c_int, c_int, _fp, _fp, _fp, _fp, POINTER(c_int),
                                     c_void_p]),
+    "ttsx_t1_set_plan": (c_int, [c_void_p, c_int]),
     "ttsx_t1_postnet_run": (c_int, [c_void_p, _fp, _fp, c_int, c_int, _fp, c_void_p]),
     "ttsx_spec_to_mag": (c_int, [_fp, _fp, c_int, c_int, c_int, c_int, POINTER(AudioParams), _fp, c_void_p]),
     "ttsx_griffin_lim": (c_int, [_fp, _fp, _fp, c_int, c_int, POINTER(StftParams), c_int, c_float, _fp,

@@ -20,6 +20,7 @@
 
 #include "conv_mfma.h"
 #include "t1_steps.h"
+#include "t1_team.h"
 
 using convmfma::Layer;
 
@@ -526,6 +527,8 @@ __global__ void transpose_loc_conv_kernel(float* __restrict__ conv_t, const floa
 struct ttsx_t1 {
   int r, memory_size, linear_dim;
   t1_steps* steps;  // decoder as a chain of launches over the whole chip (null: memory queue too long for it)
+  t1_team* team;    // decoder as one persistent launch with on-chip weights, batch 1-2 (null: other geometry)
+  int plan;         // ttsx_t1_set_plan: -1 by shape, 0 launch chain, 1 team kernel, 2 one workgroup per utterance
   Layer enc_pre[2], annot, last;
   Cbhg enc_cbhg, post_cbhg;
   // decoder weights (own copies, reference layouts)
@@ -556,7 +559,7 @@ extern "C" int ttsx_t1_create(const ttsx_t1_weights* w, int r, int memory_size, 
   hipStream_t st = static_cast<hipStream_t>(stream);
   ttsx_t1* m = new ttsx_t1();
   ScopeExit on_fail([&] { (void)ttsx_t1_destroy(m); });
-  m->steps = nullptr;
+  m->steps = nullptr, m->team = nullptr, m->plan = -1;
   m->r = r, m->memory_size = memory_size, m->linear_dim = linear_dim;
   m->ws_a = m->ws_b = m->ws_annot = m->post_out = nullptr;
   m->cap_rows_enc = m->cap_rows_post = m->cap_annot = 0;
@@ -629,6 +632,7 @@ extern "C" int ttsx_t1_create(const ttsx_t1_weights* w, int r, int memory_size, 
     sw.att_init = d.att_init, sw.mem_init = d.mem_init, sw.rnn_inits = d.rnn_inits;
     sw.mem_dim = mem_dim, sw.odim = odim;
     if ((rc = t1_steps_create(&sw, st, &m->steps))) return rc;
+    if ((rc = t1_team_create(&sw, st, &m->team))) return rc;
   }
   TTSX_HIP(hipStreamSynchronize(st));
   on_fail.dismiss();
@@ -644,6 +648,7 @@ extern "C" int ttsx_t1_destroy(ttsx_t1* m) {
   cbhg_destroy(&m->enc_cbhg);
   cbhg_destroy(&m->post_cbhg);
   t1_steps_destroy(m->steps);
+  t1_team_destroy(m->team);
   for (float* p : m->owned) (void)hipFree(p);
   float* bufs[] = {m->ws_a, m->ws_b, m->ws_annot, m->post_out};
   for (float* b : bufs)
@@ -689,10 +694,15 @@ extern "C" int ttsx_t1_decoder_run(ttsx_t1* m, const float* enc, const int32_t* 
   // processed annotations, once per utterance (LocationSensitiveAttention caches them, :82-83)
   int rc = convmfma::layer_run(m->annot, enc, ENC_D, m->ws_annot, ATT_D, 0, nullptr, 0, nullptr, B, T, st);
   if (rc) return rc;
-  // Default: eight launches per step over the whole chip.  TTSX_T1_PERSISTENT=1 (or a memory queue longer
-  // than 512 floats): the whole loop of an utterance in one workgroup.
-  const char* pers = getenv("TTSX_T1_PERSISTENT");
-  if (m->steps && !(pers && pers[0] == '1'))
+  // Batch 1-2 with a text of up to 128 symbols: one persistent launch of a 33-workgroup team per utterance with
+  // all decoder weights on chip (t1_team.hip).  Otherwise seven launches per step over the whole chip
+  // (t1_steps, in t2_decoder.hip); a memory queue longer than 512 floats leaves only the
+  // one-workgroup-per-utterance kernel below.  ttsx_t1_set_plan overrides the choice where the shapes allow.
+  const bool team_ok = t1_team_supports(m->team, B, T);
+  if (team_ok && (m->plan == 1 || m->plan == -1))
+    return t1_team_run(m->team, enc, m->ws_annot, lengths, B, T, max_decoder_steps, mel, align, stop, n_steps,
+                       steps_run_host, st);
+  if (m->steps && m->plan != 2)
     return t1_steps_run(m->steps, enc, m->ws_annot, lengths, B, T, max_decoder_steps, mel, align, stop, n_steps,
                         steps_run_host, st);
   DecP d = m->dec;
@@ -709,6 +719,13 @@ extern "C" int ttsx_t1_decoder_run(ttsx_t1* m, const float* enc, const int32_t* 
   int run = 0;
   for (int b = 0; b < B; ++b) run = std::max(run, (int)host[b]);
   if (steps_run_host) *steps_run_host = run;
+  return TTSX_OK;
+}
+
+extern "C" int ttsx_t1_set_plan(ttsx_t1* m, int decoder) {
+  TTSX_ARG(m, "ttsx_t1_set_plan: null handle");
+  TTSX_ARG(decoder >= -1 && decoder <= 2, "ttsx_t1_set_plan: decoder=%d is not -1, 0, 1 or 2", decoder);
+  m->plan = decoder;
   return TTSX_OK;
 }
 

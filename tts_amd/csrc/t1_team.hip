@@ -1,0 +1,833 @@
+// Tacotron (v1) greedy decoder for batch 1-2: one persistent launch per run, every decoder weight resident on
+// chip for the whole utterance.
+//
+// What a step computes follows Decoder.forward in eval mode (Tacotron/TTS/models.py:586-640) with Prenet
+// (:250-253), AttentionRNNCell.forward (:124-156), LocationSensitiveAttention.forward (:71-88), the two residual
+// decoder GRUs (:612-620), proj_to_mel + sigmoid (:622-623), StopNet (:663-667) and the stop rule (:635-640).
+//
+// The decoder is 1.66 M parameters (6.7 MB).  As a chain of launches a step costs seven launch boundaries
+// (~4.4 us each) for a microsecond of arithmetic; here a TEAM of 33 workgroups per utterance runs the whole loop:
+//   * 32 "row" workgroups of 8 waves.  Workgroup g owns hidden units 8g .. 8g+7 of each of the three GRUs (one
+//     unit per wave), rows 8g .. 8g+7 of prenet layer 1 and of project_to_decoder_in, rows 5g .. 5g+4 of
+//     proj_to_mel and its 8 columns of the query layer.  Those weights (124 floats per thread) stay in REGISTERS
+//     from the first step to the last; prenet layer 2 (128 x 256), which every workgroup evaluates in full, sits
+//     in LDS.  Nothing but activations crosses the chip after the first microseconds.
+//   * 1 attention workgroup: keeps the utterance's annotations and encoder outputs in registers (T <= 128), the
+//     location-layer weights and both alignment rows in LDS; per step it adds up the 32 query shares, evaluates
+//     the energies, normalises, and publishes the context.
+// Activations travel through small exchange buffers in global memory as 64-bit words (step tag, value): a
+// consumer re-reads its elements until all of them carry the tag of the step it needs, so an exchange costs one
+// store-to-load round trip and needs neither counters nor fences.  Coherent polling reads are served by the
+// memory side of the chip at about one 128-byte line per 0.5 ns per channel, and 256 waves that each re-read a
+// whole vector saturate that (measured: 2.3 us per exchange with one word per lane and poll, 5.4 us with eight).
+// So a workgroup polls every word ONCE (thread i polls word i and shares it through LDS), and a producer
+// writes a word to eight replicas (lanes 0-7 of the publishing wave, one store instruction) that lie in
+// different channels; workgroup g reads replica g mod 8.  Six exchanges per step lie on the serial
+// chain (x1 | h_att + query shares | context | h1, d1 | d2 | frames).  GRU 1 takes input weights composed with
+// project_to_decoder_in (fp64, once), which saves a seventh.  Buffers are double-buffered by step parity: a
+// vector that a phase both reads (previous step) and rewrites cannot be overwritten under a slow reader.
+// Every workgroup, the attention one included, evaluates the stop rule of a step itself from the published
+// frames (same instructions, same result), so the team leaves the loop together.  Every wait is bounded: a wave
+// that sees no progress for ~2 s raises an abort word that ends all other waits, and the host reports it.
+#include <vector>
+
+#include "common.h"
+#include "t1_team.h"
+
+namespace {
+
+typedef unsigned long long u64;
+
+constexpr int TG = 32;            // row workgroups per team
+constexpr int TEAM = TG + 1;      // + the attention workgroup
+constexpr int NT = 512;
+constexpr int MEM = 400, ODIM = 160, PRE0 = 256, PRE1 = 128, RNN = 256, ENC = 256, ATT = 128;
+constexpr int LOCF = 32, LOCK = 31, LPAD = 15, TMAX = 128;
+constexpr long SPIN_LIMIT = 4000000;
+
+// ---- per-thread register image: slot s of thread tid of row workgroup g at img[(g * NS + s) * NT + tid]
+enum {
+  S_P1 = 0,                                                   // 7: prenet-1 row 8g+w, k = lane + 64 j
+  S_A_RX = 7, S_A_ZX = 13, S_A_NX = 19,                       // 6 each: attention GRU input rows over [x2; ctx]
+  S_A_RH = 25, S_A_ZH = 29, S_A_NH = 33,                      // 4 each: attention GRU recurrent rows
+  S_QS = 37,                                                  // 8: W_q[d = tid][8g + j] (threads < 128)
+  S_1_RC = 45, S_1_ZC = 53, S_1_NC = 61,                      // 8 each: GRU 1 input rows composed over [h_att; ctx]
+  S_1_RH = 69, S_1_ZH = 73, S_1_NH = 77,                      // 4 each
+  S_D0 = 81,                                                  // 8: project_to_decoder_in row 8g+w
+  S_2_RX = 89, S_2_ZX = 93, S_2_NX = 97, S_2_RH = 101, S_2_ZH = 105, S_2_NH = 109,  // 4 each: GRU 2
+  S_MEL = 113,                                                // 4: proj_to_mel row 5g+w (waves 0..4)
+  S_STOP = 117,                                               // 7: stopnet weights over [d2; frames]
+  S_B_P1 = 124, S_B_A = 125 /* r, z, n_in, n_h */, S_B_1 = 129 /* r, z, n_in, n_h, d0 */, S_B_2 = 134, S_B_MEL = 138,
+  S_B_STOP = 139,
+  NS = 140
+};
+
+// ---- exchange buffers of one team (u64 words); [2] = step parity
+constexpr int X_OUT = 0, X_OUT_N = 192, X_X1 = X_OUT + 2 * X_OUT_N, X_HATT = X_X1 + 2 * 256, X_QS = X_HATT + 2 * 256,
+              X_QS_N = TG * ATT, X_CTX = X_QS + 2 * X_QS_N, X_CTX_N = 320 /* 256 + a_last at [256] */,
+              X_H1 = X_CTX + 2 * X_CTX_N, X_D1 = X_H1 + 2 * 256, X_H2 = X_D1 + 2 * 256, X_D2 = X_H2 + 2 * 256,
+              X_TOTAL = X_D2 + 2 * 256;
+constexpr int NREP = 8;                 // replicas of every exchange buffer but the query shares
+constexpr int X_REP = X_TOTAL + 544;    // replica stride in words (not a multiple of 4 KB: replicas in different channels)
+constexpr int X_TEAM = NREP * X_REP;    // words per team
+
+struct TeamP {
+  const float* img;      // [TG][NS][NT]
+  const float* w2t;      // [256][128] prenet layer 2, transposed (k-major)
+  const float* b2;       // [128]
+  const float *mem_init, *att_init, *rnn_inits;
+  const float *loc_conv_t /* [62][32] */, *loc_lin_w /* [128][32] */, *q_bias /* [128] query + location-linear bias */, *v_w;
+  const float *stop_w, *stop_b;  // [416], [1]
+  const float *enc, *annot;      // [B][T][256], [B][T][128]
+  const int32_t* len;            // [B] or null
+  u64* xch;                      // [B][X_TEAM]
+  int* abort_word;
+  float *mel, *align, *stop;
+  int32_t* n_steps;
+  int T, max_steps;
+};
+
+#ifdef TTSX_TEAM_TIMING
+// Tuning build: workgroup 0 / the attention workgroup of utterance 0 leave 100 MHz timestamps of step 50.
+__device__ long long team_marks[64];
+#define TEAM_MARK(cond, i)                                            \
+  do {                                                                \
+    if ((cond) && t == 50 && threadIdx.x == 0) team_marks[i] = wall_clock64(); \
+  } while (0)
+#else
+#define TEAM_MARK(cond, i) \
+  do {                     \
+  } while (0)
+#endif
+
+__device__ __forceinline__ void publish(u64* X, int idx, float v, unsigned tag) {
+  __hip_atomic_store(X + idx, ((u64)tag << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// A wave-uniform value to word `idx` of all replicas: lanes 0 .. NREP-1 store one replica each.
+__device__ __forceinline__ void publish_all(u64* X, int idx, float v, unsigned tag, int lane) {
+  if (lane < NREP) publish(X + (size_t)lane * X_REP, idx, v, tag);
+}
+
+// One word per thread (none where !active; thread 0 of the workgroup may poll a second one): re-read until all
+// words of the wave carry `tag`.  False: aborted (the caller must still reach the barrier that follows).
+template <bool SECOND>
+__device__ __forceinline__ bool poll(const u64* a, bool active, const u64* a2, unsigned tag, float* val, float* val2,
+                                     int* abort_word) {
+  for (long spin = 0;; ++spin) {
+    u64 v = (u64)tag << 32, v2 = (u64)tag << 32;
+    if (active) v = __hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (SECOND && threadIdx.x == 0) v2 = __hip_atomic_load(a2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool ok = (unsigned)(v >> 32) == tag && (unsigned)(v2 >> 32) == tag;
+    *val = __uint_as_float((unsigned)v);
+    if (SECOND) *val2 = __uint_as_float((unsigned)v2);
+    if (__all(ok)) return true;
+    if ((spin & 127) == 127 && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
+    if (spin > SPIN_LIMIT) {
+      __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return false;
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+
+// tanh through one hardware exponential, as the energies of the launch-chain decoder compute it
+__device__ __forceinline__ float fast_tanhf(float x) {
+  const float t = __expf(2.f * x);
+  return 1.f - 2.f * __builtin_amdgcn_rcpf(t + 1.f);
+}
+
+// Sum over the 64 lanes on the DPP network (a __shfl_xor butterfly goes through the LDS crossbar: ~100 cycles per
+// step, and a step of the decoder holds sixteen such sums).  Every lane gets the total; the order of the
+// additions is fixed, so every workgroup that reduces the same values gets the same bits.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float wsum(float v) {
+  v = dpp_add<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
+  v = dpp_add<0x141, 0xf>(v);  // row_half_mirror
+  v = dpp_add<0x140, 0xf>(v);  // row_mirror: every lane of a row holds the row's sum
+  v = dpp_add<0x142, 0xa>(v);  // row_bcast15 into rows 1 and 3
+  v = dpp_add<0x143, 0xc>(v);  // row_bcast31 into rows 2 and 3: lane 63 holds the total
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+template <int N>
+__device__ __forceinline__ void load_init(const float* src, int n, float (&x)[N], int lane) {
+#pragma unroll
+  for (int j = 0; j < N; ++j) x[j] = lane + 64 * j < n ? src[lane + 64 * j] : 0.f;
+}
+
+// element `u` (wave-uniform) of a vector held as x[j] = v[lane + 64 j]
+template <int N>
+__device__ __forceinline__ float pick(const float (&x)[N], int u) {
+  float v = x[0];
+#pragma unroll
+  for (int j = 1; j < N; ++j) v = (u >> 6) == j ? x[j] : v;
+  return __shfl(v, u & 63, 64);
+}
+
+// StopNet on [d2; frames] (Tacotron/TTS/models.py:663-667) and the stop rule (:635-640) of the step with 1-based
+// index tn.  Every workgroup of the team runs exactly this, so all of them take the same decision.
+__device__ __forceinline__ bool stop_rule(const float (&ws)[7], float bs, const float (&d2)[4], const float (&out)[3],
+                                          float a_last, int tn, int len, int max_steps, float* token) {
+  float acc = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc += ws[j] * d2[j];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) acc += ws[4 + j] * out[j];
+  const float s = sigmoidf_(wsum(acc) + bs);
+  *token = s;
+  return ((float)tn > (float)len / 4.f && (s > 0.6f || a_last > 0.6f)) || tn > max_steps;
+}
+
+__device__ __forceinline__ float gru_new(float sr, float sz, float sni, float snh, float h_old) {
+  const float r = sigmoidf_(sr), z = sigmoidf_(sz);
+  const float n = tanhf(sni + r * snh);
+  return (1.f - z) * n + z * h_old;
+}
+
+// ------------------------------------------------------------------ a row workgroup
+// LDS of a row workgroup (floats)
+constexpr int RL_W2 = 0, RL_B2 = RL_W2 + PRE0 * PRE1, RL_PART = RL_B2 + PRE1, RL_X1 = RL_PART + 4 * PRE1,
+              RL_HN = RL_X1 + PRE0, RL_FLAG = RL_HN + 8, RL_RING = RL_FLAG + 8, RL_OUT = RL_RING + MEM,
+              RL_HC = RL_OUT + 192, RL_D1 = RL_HC + 576, RL_D2 = RL_D1 + 512, RL_TOTAL = RL_D2 + 512;
+
+__device__ void row_workgroup(const TeamP& p, int b, int g, float* sm) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int u = 8 * g + wave;  // this wave's hidden unit / prenet row / project_to_decoder_in row
+  float* s_w2 = sm + RL_W2;      // [256][128]
+  float* s_b2 = sm + RL_B2;      // [128]
+  float* s_part = sm + RL_PART;  // [4][128]
+  float* s_x1 = sm + RL_X1;      // [256]
+  float* s_hn = sm + RL_HN;      // [8]
+  int* s_flag = reinterpret_cast<int*>(sm + RL_FLAG);
+  float* ring = sm + RL_RING;    // [400] memory queue
+  float* s_out = sm + RL_OUT;    // [160] frames of the previous step
+  float* s_hc = sm + RL_HC;      // [256] h_att, [256] context, [1] alignment at the last position
+  float* s_d1 = sm + RL_D1;      // [256] d1, [256] h1
+  float* s_d2 = sm + RL_D2;      // [256] d2, [256] h2
+  u64* X = p.xch + (size_t)b * X_TEAM;                  // publishing base (replica 0)
+  const u64* Xr = X + (size_t)(g % NREP) * X_REP;        // the replica this workgroup reads
+  int* ab = p.abort_word;
+  const int len = p.len ? min(max(p.len[b], 1), p.T) : p.T;
+
+  float w[NS];
+  {
+    const float* img = p.img + ((size_t)g * NS) * NT + tid;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) w[s] = img[(size_t)s * NT];
+  }
+  for (int i = tid; i < PRE0 * PRE1; i += NT) s_w2[i] = p.w2t[i];
+  if (tid < PRE1) s_b2[tid] = p.b2[tid];
+  for (int i = tid; i < MEM; i += NT) ring[i] = p.mem_init[i];
+  if (tid == 0) *s_flag = 0;
+  int head = 0;
+  __syncthreads();
+
+  // Recurrent state as every wave needs it (element lane + 64 j of each vector).  A vector published in step t is
+  // fetched once, in step t, together with the vector whose arrival the workgroup waits for anyway, and kept.
+  float hatt[4], ctx[4] = {0.f, 0.f, 0.f, 0.f}, h1[4], h2[4], xd2[4] = {0.f, 0.f, 0.f, 0.f};
+  float a_last = 0.f;
+  load_init<4>(p.att_init, RNN, hatt, lane);
+  load_init<4>(p.rnn_inits, RNN, h1, lane);
+  load_init<4>(p.rnn_inits + RNN, RNN, h2, lane);
+  for (int t = 0;; ++t) {
+    const unsigned tag = (unsigned)t + 1u;  // what this step publishes; the previous step's data carries tag - 1
+    const int cur = t & 1, prv = cur ^ 1;
+    TEAM_MARK(b == 0 && g == 0, 0);
+    if (t > 0) {
+      // ---- the previous step's frames: into the memory queue; its stop rule
+      {
+        float v, v2;
+        const bool ok = poll<false>(Xr + X_OUT + prv * X_OUT_N + tid, tid < ODIM, nullptr, tag - 1, &v, &v2, ab);
+        if (tid < ODIM) {
+          int ph = head + tid;
+          ph = ph >= MEM ? ph - MEM : ph;
+          ring[ph] = v;
+          s_out[tid] = v;
+        }
+        if (!ok) *s_flag = 1;
+        __syncthreads();
+        if (*s_flag) return;
+      }
+      head = head + ODIM >= MEM ? head + ODIM - MEM : head + ODIM;
+      float xo[3], ws[7];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) xo[j] = lane + 64 * j < ODIM ? s_out[lane + 64 * j] : 0.f;
+#pragma unroll
+      for (int j = 0; j < 7; ++j) ws[j] = w[S_STOP + j];
+      float token;
+      const bool done = stop_rule(ws, w[S_B_STOP], xd2, xo, a_last, t, len, p.max_steps, &token);
+      if (g == 0 && wave == 0 && lane == 0) {
+        p.stop[(size_t)b * (p.max_steps + 1) + (t - 1)] = token;
+        if (done) p.n_steps[b] = t;
+      }
+      if (done) return;
+    }
+    TEAM_MARK(b == 0 && g == 0, 1);
+    // ---- prenet layer 1: row u over the memory queue
+    {
+      float acc = 0.f;
+#pragma unroll
+      for (int j = 0; j < 7; ++j) {
+        const int k = lane + 64 * j;
+        int ph = head + k;
+        ph = ph >= MEM ? ph - MEM : ph;
+        const float xm = k < MEM ? ring[ph] : 0.f;
+        acc += w[S_P1 + j] * xm;
+      }
+      const float x1 = fmaxf(wsum(acc) + w[S_B_P1], 0.f);
+      publish_all(X + X_X1 + cur * 256, u, x1, tag, lane);
+    }
+    TEAM_MARK(b == 0 && g == 0, 2);
+    // ---- prenet layer 2, whole, by every workgroup: thread (row, quarter of K)
+    float x2[2];
+    {
+      {
+        float v, v2;
+        const bool ok = poll<false>(Xr + X_X1 + cur * 256 + tid, tid < PRE0, nullptr, tag, &v, &v2, ab);
+        if (tid < PRE0) s_x1[tid] = v;
+        if (!ok) *s_flag = 1;
+        __syncthreads();
+        if (*s_flag) return;
+      }
+      TEAM_MARK(b == 0 && g == 0, 3);
+      const int kq = wave >> 1, row = (wave & 1) * 64 + lane;
+      float acc = 0.f;
+      const float* wcol = s_w2 + (size_t)(64 * kq) * PRE1 + row;
+      const float* xs = s_x1 + 64 * kq;
+#pragma unroll 16
+      for (int k = 0; k < 64; ++k) acc += wcol[k * PRE1] * xs[k];
+      s_part[kq * PRE1 + row] = acc;
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int r = lane + 64 * j;
+        x2[j] = fmaxf(((s_part[r] + s_part[PRE1 + r]) + (s_part[2 * PRE1 + r] + s_part[3 * PRE1 + r])) + s_b2[r], 0.f);
+      }
+    }
+    TEAM_MARK(b == 0 && g == 0, 4);
+    // ---- attention GRU, unit u, on [x2; ctx(t-1)] and h_att(t-1); the workgroup's share of the query
+    {
+      float sr = 0.f, sz = 0.f, sni = 0.f, snh = 0.f;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const float x = j < 2 ? x2[j] : ctx[j - 2];
+        sr += w[S_A_RX + j] * x, sz += w[S_A_ZX + j] * x, sni += w[S_A_NX + j] * x;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float h = hatt[j];
+        sr += w[S_A_RH + j] * h, sz += w[S_A_ZH + j] * h, snh += w[S_A_NH + j] * h;
+      }
+      sr = wsum(sr) + w[S_B_A], sz = wsum(sz) + w[S_B_A + 1];
+      sni = wsum(sni) + w[S_B_A + 2], snh = wsum(snh) + w[S_B_A + 3];
+      const float hn = gru_new(sr, sz, sni, snh, pick<4>(hatt, u));
+      publish_all(X + X_HATT + cur * 256, u, hn, tag, lane);
+      if (lane == 0) s_hn[wave] = hn;
+      __syncthreads();
+      if (tid < ATT) {
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) q += w[S_QS + j] * s_hn[j];
+        publish(X + X_QS + cur * X_QS_N, g * ATT + tid, q, tag);
+      }
+    }
+    TEAM_MARK(b == 0 && g == 0, 5);
+    // ---- GRU 1 (input weights composed with project_to_decoder_in) on [h_att; ctx] and h1(t-1); d0
+    float d1_u;
+    {
+      {
+        float v, v2;
+        const u64* a = tid < RNN ? Xr + X_HATT + cur * 256 + tid : Xr + X_CTX + cur * X_CTX_N + (tid - RNN);
+        const bool ok = poll<true>(a, true, Xr + X_CTX + cur * X_CTX_N + ENC, tag, &v, &v2, ab);
+        s_hc[tid] = v;
+        if (tid == 0) s_hc[RNN + ENC] = v2;  // the alignment at the utterance's last position
+        if (!ok) *s_flag = 1;
+        __syncthreads();
+        if (*s_flag) return;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) hatt[j] = s_hc[lane + 64 * j], ctx[j] = s_hc[RNN + lane + 64 * j];
+        a_last = s_hc[RNN + ENC];
+      }
+      TEAM_MARK(b == 0 && g == 0, 6);
+      float sr = 0.f, sz = 0.f, sni = 0.f, snh = 0.f, sd = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        sr += w[S_1_RC + j] * hatt[j] + w[S_1_RC + 4 + j] * ctx[j], sz += w[S_1_ZC + j] * hatt[j] + w[S_1_ZC + 4 + j] * ctx[j];
+        sni += w[S_1_NC + j] * hatt[j] + w[S_1_NC + 4 + j] * ctx[j], sd += w[S_D0 + j] * hatt[j] + w[S_D0 + 4 + j] * ctx[j];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) sr += w[S_1_RH + j] * h1[j], sz += w[S_1_ZH + j] * h1[j], snh += w[S_1_NH + j] * h1[j];
+      sr = wsum(sr) + w[S_B_1], sz = wsum(sz) + w[S_B_1 + 1];
+      sni = wsum(sni) + w[S_B_1 + 2], snh = wsum(snh) + w[S_B_1 + 3];
+      const float d0 = wsum(sd) + w[S_B_1 + 4];
+      const float hn = gru_new(sr, sz, sni, snh, pick<4>(h1, u));
+      d1_u = hn + d0;
+      publish_all(X + X_H1 + cur * 256, u, hn, tag, lane);
+      publish_all(X + X_D1 + cur * 256, u, d1_u, tag, lane);
+    }
+    TEAM_MARK(b == 0 && g == 0, 7);
+    // ---- GRU 2 on d1 and h2(t-1); d2 = h2 + d1
+    {
+      float x[4];
+      {
+        float v, v2;
+        const u64* a = tid < RNN ? Xr + X_D1 + cur * 256 + tid : Xr + X_H1 + cur * 256 + (tid - RNN);
+        const bool ok = poll<false>(a, true, nullptr, tag, &v, &v2, ab);
+        s_d1[tid] = v;
+        if (!ok) *s_flag = 1;
+        __syncthreads();
+        if (*s_flag) return;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x[j] = s_d1[lane + 64 * j], h1[j] = s_d1[RNN + lane + 64 * j];
+      }
+      TEAM_MARK(b == 0 && g == 0, 8);
+      float sr = 0.f, sz = 0.f, sni = 0.f, snh = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        sr += w[S_2_RX + j] * x[j] + w[S_2_RH + j] * h2[j];
+        sz += w[S_2_ZX + j] * x[j] + w[S_2_ZH + j] * h2[j];
+        sni += w[S_2_NX + j] * x[j], snh += w[S_2_NH + j] * h2[j];
+      }
+      sr = wsum(sr) + w[S_B_2], sz = wsum(sz) + w[S_B_2 + 1];
+      sni = wsum(sni) + w[S_B_2 + 2], snh = wsum(snh) + w[S_B_2 + 3];
+      const float hn = gru_new(sr, sz, sni, snh, pick<4>(h2, u));
+      publish_all(X + X_H2 + cur * 256, u, hn, tag, lane);
+      publish_all(X + X_D2 + cur * 256, u, hn + d1_u, tag, lane);
+    }
+    TEAM_MARK(b == 0 && g == 0, 9);
+    // ---- frames: row 5g + wave of proj_to_mel (waves 0..4), sigmoid
+    {
+      float v, v2;
+      const u64* a = tid < RNN ? Xr + X_D2 + cur * 256 + tid : Xr + X_H2 + cur * 256 + (tid - RNN);
+      const bool ok = poll<false>(a, true, nullptr, tag, &v, &v2, ab);
+      s_d2[tid] = v;
+      if (!ok) *s_flag = 1;
+      __syncthreads();
+      if (*s_flag) return;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xd2[j] = s_d2[lane + 64 * j], h2[j] = s_d2[RNN + lane + 64 * j];
+    }
+    TEAM_MARK(b == 0 && g == 0, 10);
+    if (wave < 5) {
+      float acc = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc += w[S_MEL + j] * xd2[j];
+      const float o = sigmoidf_(wsum(acc) + w[S_B_MEL]);
+      const int row = 5 * g + wave;
+      publish_all(X + X_OUT + cur * X_OUT_N, row, o, tag, lane);
+      if (lane == 0) p.mel[((size_t)b * (p.max_steps + 1) + t) * ODIM + row] = o;
+    }
+    TEAM_MARK(b == 0 && g == 0, 11);
+  }
+}
+
+// ------------------------------------------------------------------ the attention workgroup
+__device__ void attention_workgroup(const TeamP& p, int b, float* sm) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int T = p.T, len = p.len ? min(max(p.len[b], 1), T) : T;
+  float* s_wl = sm;                                  // [62][32] location conv, filter fastest
+  float* s_wld = s_wl + 2 * LOCK * LOCF;             // [128][32] location linear layer
+  float* s_v = s_wld + ATT * LOCF;                   // [128]
+  float* s_qb = s_v + ATT;                           // [128] query bias + location-linear bias
+  float* s_a = s_qb + ATT;                           // [2][TMAX + 32] previous / cumulative alignment, 15 zeros in front
+  float* s_cf = s_a + 2 * (TMAX + 32);               // [TMAX][33]
+  float* s_qp = s_cf + TMAX * (LOCF + 1);            // [4][128]
+  float* s_ep = s_qp + 4 * ATT;                      // [4][TMAX]
+  float* s_al = s_ep + 4 * TMAX;                     // [TMAX]
+  float* s_cp = s_al + TMAX;                         // [2][256]
+  float* s_red = s_cp + 2 * ENC;                     // [8]
+  float* s_st = s_red + 8;                           // [256] d2, [160] frames: inputs of the stop rule
+  int* s_flag = reinterpret_cast<int*>(s_st + 512);
+  u64* X = p.xch + (size_t)b * X_TEAM;               // replica 0: this workgroup's reads; base of what it publishes
+  int* ab = p.abort_word;
+  const float* enc = p.enc + (size_t)b * T * ENC;
+  const float* annot = p.annot + (size_t)b * T * ATT;
+
+  for (int i = tid; i < 2 * LOCK * LOCF; i += NT) s_wl[i] = p.loc_conv_t[i];
+  for (int i = tid; i < ATT * LOCF; i += NT) s_wld[i] = p.loc_lin_w[i];
+  if (tid < ATT) s_v[tid] = p.v_w[tid], s_qb[tid] = p.q_bias[tid];
+  for (int i = tid; i < 2 * (TMAX + 32); i += NT) s_a[i] = 0.f;
+  if (tid == 0) *s_flag = 0;
+  // energy role: position pos, attention dims 32 dq .. 32 dq + 31 (a wave has one dq: the weights it reads from
+  // LDS are broadcasts, and no sum crosses lanes)
+  const int pos = tid & (TMAX - 1), dq = tid >> 7;
+  float pa[32];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) pa[i] = pos < len ? annot[(size_t)pos * ATT + 32 * dq + i] : 0.f;
+  // query role: dim d, shares 8 tg .. 8 tg + 7
+  const int d = tid & (ATT - 1), tg = tid >> 7;
+  // context role: column c, positions 64 th .. 64 th + 63
+  const int c = tid & (ENC - 1), th = tid >> 8;
+  float er[64];
+#pragma unroll
+  for (int i = 0; i < 64; ++i) {
+    const int ps = 64 * th + i;
+    er[i] = ps < len ? enc[(size_t)ps * ENC + c] : 0.f;
+  }
+  float ws[7];
+#pragma unroll
+  for (int j = 0; j < 7; ++j) ws[j] = lane + 64 * j < RNN + ODIM ? p.stop_w[lane + 64 * j] : 0.f;
+  const float bs = p.stop_b[0];
+  __syncthreads();
+
+  // Location conv, thread (filter f, 8 positions), then the location-linear layer: pl[i] = annot[pos][d] +
+  // (W_ld . conv features of pos)[d].  Both depend on earlier alignments only, so the workgroup evaluates them for
+  // the coming step right after it has published a context, while the row workgroups run their GRUs.
+  float pl[32];
+  auto location_terms = [&]() {
+    {
+      const int f = tid & 31, tp = tid >> 5;
+      float acc[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+#pragma unroll
+      for (int ch = 0; ch < 2; ++ch) {
+        const float* a = s_a + ch * (TMAX + 32) + 8 * tp;
+        float win[LOCK + 7];
+#pragma unroll
+        for (int j = 0; j < LOCK + 7; ++j) win[j] = a[j];
+#pragma unroll
+        for (int j = 0; j < LOCK; ++j) {
+          const float wv = s_wl[(ch * LOCK + j) * LOCF + f];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) acc[i] += wv * win[j + i];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s_cf[(8 * tp + i) * (LOCF + 1) + f] = acc[i];
+    }
+    __syncthreads();
+    float cf[LOCF];
+#pragma unroll
+    for (int f = 0; f < LOCF; ++f) cf[f] = s_cf[pos * (LOCF + 1) + f];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      const float4* wl = reinterpret_cast<const float4*>(s_wld + (32 * dq + i) * LOCF);
+      float loc = 0.f;
+#pragma unroll
+      for (int f4 = 0; f4 < LOCF / 4; ++f4) {
+        const float4 w4 = wl[f4];
+        loc += w4.x * cf[4 * f4] + w4.y * cf[4 * f4 + 1] + w4.z * cf[4 * f4 + 2] + w4.w * cf[4 * f4 + 3];
+      }
+      pl[i] = pa[i] + loc;
+      // the value is needed HERE, before the next wait (the compiler would otherwise sink the arithmetic behind
+      // the wait and hold all 256 weight reads across it)
+      asm volatile("" : "+v"(pl[i])::"memory");
+    }
+  };
+  location_terms();
+  for (int t = 0;; ++t) {
+    const unsigned tag = (unsigned)t + 1u;
+    const int cur = t & 1;
+    TEAM_MARK(b == 0, 17);
+    // ---- query = sum of the 32 shares: thread (d, tg) adds 8 of them (every word is read by this thread only)
+    {
+      const u64* Q = X + X_QS + cur * X_QS_N + (size_t)(8 * tg) * ATT + d;
+      float acc = 0.f;
+      bool got[8] = {false, false, false, false, false, false, false, false};
+      float val[8];
+      bool fail = false;
+      for (long spin = 0;; ++spin) {
+        bool ok = true;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          if (!got[j]) {
+            const u64 v = __hip_atomic_load(Q + (size_t)j * ATT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            got[j] = (unsigned)(v >> 32) == tag;
+            val[j] = __uint_as_float((unsigned)v);
+          }
+          ok = ok && got[j];
+        }
+        if (__all(ok)) break;
+        if ((spin & 127) == 127 && __hip_atomic_load(ab, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) fail = true;
+        if (spin > SPIN_LIMIT) {
+          __hip_atomic_store(ab, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          fail = true;
+        }
+        if (fail) break;
+        __builtin_amdgcn_s_sleep(1);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc += val[j];
+      s_qp[tg * ATT + d] = acc;
+      if (fail) *s_flag = 1;
+    }
+    __syncthreads();
+    if (*s_flag) return;
+    TEAM_MARK(b == 0, 18);
+    // ---- energies: e[pos] = sum_d v[d] tanh(q[d] + annot[pos][d] + (W_ld cf[pos])[d])
+    {
+      float e = 0.f;
+#pragma unroll
+      for (int i = 0; i < 32; ++i) {
+        const int dd = 32 * dq + i;
+        const float q = ((s_qp[dd] + s_qp[ATT + dd]) + (s_qp[2 * ATT + dd] + s_qp[3 * ATT + dd])) + s_qb[dd];
+        e += s_v[dd] * fast_tanhf(q + pl[i]);
+      }
+      s_ep[dq * TMAX + pos] = e;
+    }
+    __syncthreads();
+    TEAM_MARK(b == 0, 19);
+    // ---- sigmoid normalisation over the utterance's own positions; state update; alignment row
+    {
+      float s = 0.f;
+      if (tid < TMAX && tid < len)
+        s = sigmoidf_((s_ep[tid] + s_ep[TMAX + tid]) + (s_ep[2 * TMAX + tid] + s_ep[3 * TMAX + tid]));
+      const float part = wsum(s);
+      if (lane == 0) s_red[wave] = part;
+      __syncthreads();
+      const float sum = s_red[0] + s_red[1];
+      if (tid < TMAX) {
+        const float a = s / sum;
+        s_al[tid] = a;
+        s_a[LPAD + tid] = a;
+        s_a[(TMAX + 32) + LPAD + tid] += a;
+        if (tid < T) p.align[((size_t)b * (p.max_steps + 1) + t) * T + tid] = a;
+      }
+    }
+    __syncthreads();
+    TEAM_MARK(b == 0, 20);
+    // ---- context
+    {
+      float acc = 0.f;
+#pragma unroll
+      for (int i = 0; i < 64; ++i) acc += s_al[64 * th + i] * er[i];
+      s_cp[th * ENC + c] = acc;
+    }
+    __syncthreads();
+    {
+      const float a_last = s_al[len - 1];
+      if (tid < ENC) {
+        const float cv = s_cp[tid] + s_cp[ENC + tid];
+#pragma unroll
+        for (int r = 0; r < NREP; ++r) publish(X + (size_t)r * X_REP + X_CTX + cur * X_CTX_N, tid, cv, tag);
+      } else if (tid < ENC + NREP) {
+        publish(X + (size_t)(tid - ENC) * X_REP + X_CTX + cur * X_CTX_N, ENC, a_last, tag);
+      }
+    }
+    TEAM_MARK(b == 0, 21);
+    location_terms();  // for step t + 1 (unused if this was the last step)
+    TEAM_MARK(b == 0, 16);
+    // ---- the stop rule of this step, as every row workgroup evaluates it
+    {
+      float v, v2;
+      const u64* a = tid < RNN ? X + X_D2 + cur * 256 + tid : X + X_OUT + cur * X_OUT_N + (tid - RNN);
+      const bool ok = poll<false>(a, tid < RNN + ODIM, nullptr, tag, &v, &v2, ab);
+      s_st[tid] = v;
+      if (!ok) *s_flag = 1;
+      __syncthreads();
+      if (*s_flag) return;
+      TEAM_MARK(b == 0, 22);
+      float xd2[4], xo[3];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xd2[j] = s_st[lane + 64 * j];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) xo[j] = lane + 64 * j < ODIM ? s_st[RNN + lane + 64 * j] : 0.f;
+      float token;
+      if (stop_rule(ws, bs, xd2, xo, s_al[len - 1], t + 1, len, p.max_steps, &token)) return;
+    }
+  }
+}
+
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void t1_team_kernel(TeamP p) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int b = blockIdx.x / TEAM, g = blockIdx.x % TEAM;
+  if (g == TG) attention_workgroup(p, b, sm);
+  else row_workgroup(p, b, g, sm);
+}
+
+constexpr size_t ROW_LDS = (size_t)RL_TOTAL * sizeof(float);
+constexpr size_t ATT_LDS = (size_t)(2 * LOCK * LOCF + ATT * LOCF + 2 * ATT + 2 * (TMAX + 32) + TMAX * (LOCF + 1) + 4 * ATT +
+                                    4 * TMAX + TMAX + 2 * ENC + 8 + 512 + 8) * sizeof(float);
+constexpr size_t TEAM_LDS = ROW_LDS > ATT_LDS ? ROW_LDS : ATT_LDS;
+
+// ---- packing
+// GRU input weights composed with a preceding linear layer x = Wd y + bd:
+// w_c[row][k] = sum_j w_ih[row][j] wd[j][k], b_c[row] = b_ih[row] + sum_j w_ih[row][j] bd[j]  (fp64, one block per row)
+__global__ void compose_kernel(float* __restrict__ w_c, float* __restrict__ b_c, const float* __restrict__ w_ih,
+                               const float* __restrict__ b_ih, const float* __restrict__ wd, const float* __restrict__ bd,
+                               int kin, int ky) {
+  const int row = blockIdx.x;
+  for (int k = threadIdx.x; k < ky; k += blockDim.x) {
+    double acc = 0.0;
+    for (int j = 0; j < kin; ++j) acc += (double)w_ih[(size_t)row * kin + j] * (double)wd[(size_t)j * ky + k];
+    w_c[(size_t)row * ky + k] = (float)acc;
+  }
+  if (threadIdx.x == 0) {
+    double acc = b_ih[row];
+    for (int j = 0; j < kin; ++j) acc += (double)w_ih[(size_t)row * kin + j] * (double)bd[j];
+    b_c[row] = (float)acc;
+  }
+}
+
+struct PackP {
+  T1StepWeights w;
+  const float *wc, *bc;  // composed GRU-1 input weights [768][512], [768]
+  float *img, *w2t, *q_bias, *conv_t;
+};
+
+// a row of a [rows][K] matrix at column lane + 64 j (zero beyond K)
+__device__ __forceinline__ float at(const float* W, int row, int K, int lane, int j) {
+  const int k = lane + 64 * j;
+  return k < K ? W[(size_t)row * K + k] : 0.f;
+}
+
+__global__ void pack_team_kernel(PackP p) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < (size_t)PRE0 * PRE1) {
+    const int k = (int)(i / PRE1), r = (int)(i % PRE1);
+    p.w2t[i] = p.w.pre_w1[(size_t)r * PRE0 + k];
+  }
+  if (i < ATT) p.q_bias[i] = p.w.query_b[i] + p.w.loc_lin_b[i];
+  if (i < LOCF * 2 * LOCK) p.conv_t[(i % (2 * LOCK)) * LOCF + i / (2 * LOCK)] = p.w.loc_conv_w[i];
+  if (i >= (size_t)TG * NS * NT) return;
+  const int tid = (int)(i % NT), s = (int)((i / NT) % NS), g = (int)(i / ((size_t)NT * NS));
+  const int lane = tid & 63, wave = tid >> 6, u = 8 * g + wave;
+  const int XA = PRE1 + ENC;  // attention GRU input width
+  float v = 0.f;
+  auto in = [&](int lo, int n) { return s >= lo && s < lo + n; };
+  if (in(S_P1, 7)) v = at(p.w.pre_w0, u, MEM, lane, s - S_P1);
+  else if (in(S_A_RX, 6)) v = at(p.w.att_w_ih, u, XA, lane, s - S_A_RX);
+  else if (in(S_A_ZX, 6)) v = at(p.w.att_w_ih, RNN + u, XA, lane, s - S_A_ZX);
+  else if (in(S_A_NX, 6)) v = at(p.w.att_w_ih, 2 * RNN + u, XA, lane, s - S_A_NX);
+  else if (in(S_A_RH, 4)) v = at(p.w.att_w_hh, u, RNN, lane, s - S_A_RH);
+  else if (in(S_A_ZH, 4)) v = at(p.w.att_w_hh, RNN + u, RNN, lane, s - S_A_ZH);
+  else if (in(S_A_NH, 4)) v = at(p.w.att_w_hh, 2 * RNN + u, RNN, lane, s - S_A_NH);
+  else if (in(S_QS, 8)) v = tid < ATT ? p.w.query_w[(size_t)tid * RNN + 8 * g + (s - S_QS)] : 0.f;
+  else if (in(S_1_RC, 8)) v = at(p.wc, u, 2 * RNN, lane, s - S_1_RC);
+  else if (in(S_1_ZC, 8)) v = at(p.wc, RNN + u, 2 * RNN, lane, s - S_1_ZC);
+  else if (in(S_1_NC, 8)) v = at(p.wc, 2 * RNN + u, 2 * RNN, lane, s - S_1_NC);
+  else if (in(S_1_RH, 4)) v = at(p.w.rnn_w_hh[0], u, RNN, lane, s - S_1_RH);
+  else if (in(S_1_ZH, 4)) v = at(p.w.rnn_w_hh[0], RNN + u, RNN, lane, s - S_1_ZH);
+  else if (in(S_1_NH, 4)) v = at(p.w.rnn_w_hh[0], 2 * RNN + u, RNN, lane, s - S_1_NH);
+  else if (in(S_D0, 8)) v = at(p.w.pd_w, u, 2 * RNN, lane, s - S_D0);
+  else if (in(S_2_RX, 4)) v = at(p.w.rnn_w_ih[1], u, RNN, lane, s - S_2_RX);
+  else if (in(S_2_ZX, 4)) v = at(p.w.rnn_w_ih[1], RNN + u, RNN, lane, s - S_2_ZX);
+  else if (in(S_2_NX, 4)) v = at(p.w.rnn_w_ih[1], 2 * RNN + u, RNN, lane, s - S_2_NX);
+  else if (in(S_2_RH, 4)) v = at(p.w.rnn_w_hh[1], u, RNN, lane, s - S_2_RH);
+  else if (in(S_2_ZH, 4)) v = at(p.w.rnn_w_hh[1], RNN + u, RNN, lane, s - S_2_ZH);
+  else if (in(S_2_NH, 4)) v = at(p.w.rnn_w_hh[1], 2 * RNN + u, RNN, lane, s - S_2_NH);
+  else if (in(S_MEL, 4)) v = wave < 5 ? at(p.w.mel_w, 5 * g + wave, RNN, lane, s - S_MEL) : 0.f;
+  else if (in(S_STOP, 7)) v = at(p.w.stop_w, 0, RNN + ODIM, lane, s - S_STOP);
+  else if (s == S_B_P1) v = p.w.pre_b0[u];
+  else if (s == S_B_A) v = p.w.att_b_ih[u] + p.w.att_b_hh[u];
+  else if (s == S_B_A + 1) v = p.w.att_b_ih[RNN + u] + p.w.att_b_hh[RNN + u];
+  else if (s == S_B_A + 2) v = p.w.att_b_ih[2 * RNN + u];
+  else if (s == S_B_A + 3) v = p.w.att_b_hh[2 * RNN + u];
+  else if (s == S_B_1) v = p.bc[u] + p.w.rnn_b_hh[0][u];
+  else if (s == S_B_1 + 1) v = p.bc[RNN + u] + p.w.rnn_b_hh[0][RNN + u];
+  else if (s == S_B_1 + 2) v = p.bc[2 * RNN + u];
+  else if (s == S_B_1 + 3) v = p.w.rnn_b_hh[0][2 * RNN + u];
+  else if (s == S_B_1 + 4) v = p.w.pd_b[u];
+  else if (s == S_B_2) v = p.w.rnn_b_ih[1][u] + p.w.rnn_b_hh[1][u];
+  else if (s == S_B_2 + 1) v = p.w.rnn_b_ih[1][RNN + u] + p.w.rnn_b_hh[1][RNN + u];
+  else if (s == S_B_2 + 2) v = p.w.rnn_b_ih[1][2 * RNN + u];
+  else if (s == S_B_2 + 3) v = p.w.rnn_b_hh[1][2 * RNN + u];
+  else if (s == S_B_MEL) v = wave < 5 ? p.w.mel_b[5 * g + wave] : 0.f;
+  else if (s == S_B_STOP) v = p.w.stop_b[0];
+  p.img[i] = v;
+}
+
+}  // namespace
+
+struct t1_team {
+  float *img, *w2t, *q_bias, *conv_t;
+  const float *b2, *mem_init, *att_init, *rnn_inits, *loc_lin_w, *v_w, *stop_w, *stop_b;  // borrowed from the owner
+  u64* xch;
+  int cap_B;
+  int* abort_word;       // device
+};
+
+int t1_team_create(const T1StepWeights* w, hipStream_t st, t1_team** out) {
+  TTSX_ARG(w && out, "t1_team_create: null argument");
+  *out = nullptr;
+  if (w->mem_dim != MEM || w->odim != ODIM) return TTSX_OK;
+  t1_team* t = new t1_team();
+  memset(t, 0, sizeof(*t));
+  float *wc = nullptr, *bc = nullptr;
+  ScopeExit on_fail([&] { t1_team_destroy(t); });
+  ScopeExit free_tmp([&] { (void)hipFree(wc), (void)hipFree(bc); });
+  TTSX_HIP(hipMalloc(reinterpret_cast<void**>(&wc), sizeof(float) * 3 * RNN * 2 * RNN));
+  TTSX_HIP(hipMalloc(reinterpret_cast<void**>(&bc), sizeof(float) * 3 * RNN));
+  TTSX_HIP(hipMalloc(reinterpret_cast<void**>(&t->img), sizeof(float) * (size_t)TG * NS * NT));
+  TTSX_HIP(hipMalloc(reinterpret_cast<void**>(&t->w2t), sizeof(float) * PRE0 * PRE1));
+  TTSX_HIP(hipMalloc(reinterpret_cast<void**>(&t->q_bias), sizeof(float) * ATT));
+  TTSX_HIP(hipMalloc(reinterpret_cast<void**>(&t->conv_t), sizeof(float) * LOCF * 2 * LOCK));
+  TTSX_HIP(hipMalloc(reinterpret_cast<void**>(&t->abort_word), sizeof(int)));
+  compose_kernel<<<3 * RNN, 256, 0, st>>>(wc, bc, w->rnn_w_ih[0], w->rnn_b_ih[0], w->pd_w, w->pd_b, RNN, 2 * RNN);
+  TTSX_LAUNCH_CHECK();
+  PackP pp{*w, wc, bc, t->img, t->w2t, t->q_bias, t->conv_t};
+  const size_t n = (size_t)TG * NS * NT;
+  pack_team_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(pp);
+  TTSX_LAUNCH_CHECK();
+  t->b2 = w->pre_b1, t->mem_init = w->mem_init, t->att_init = w->att_init, t->rnn_inits = w->rnn_inits;
+  t->loc_lin_w = w->loc_lin_w, t->v_w = w->v_w, t->stop_w = w->stop_w, t->stop_b = w->stop_b;
+  TTSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(t1_team_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)TEAM_LDS));
+  TTSX_HIP(hipStreamSynchronize(st));
+  on_fail.dismiss();
+  *out = t;
+  return TTSX_OK;
+}
+
+void t1_team_destroy(t1_team* t) {
+  if (!t) return;
+  float* bufs[] = {t->img, t->w2t, t->q_bias, t->conv_t};
+  for (float* b : bufs)
+    if (b) (void)hipFree(b);
+  if (t->xch) (void)hipFree(t->xch);
+  if (t->abort_word) (void)hipFree(t->abort_word);
+  delete t;
+}
+
+#ifdef TTSX_TEAM_TIMING
+extern "C" int ttsx_debug_team_timing(long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(team_marks), sizeof(long long) * 64) == hipSuccess ? 0 : -1;
+}
+#endif
+
+bool t1_team_supports(const t1_team* t, int B, int T) { return t && B >= 1 && B <= 2 && T >= 1 && T <= TMAX; }
+
+int t1_team_run(t1_team* t, const float* enc, const float* annot, const int32_t* lengths, int B, int T,
+                int max_decoder_steps, float* mel, float* align, float* stop, int32_t* n_steps, int* steps_run_host,
+                hipStream_t st) {
+  TTSX_ARG(t && enc && annot && mel && align && stop && n_steps, "t1_team_run: null argument");
+  TTSX_ARG(t1_team_supports(t, B, T), "t1_team_run: B=%d T=%d outside what the team kernel covers", B, T);
+  if (t->cap_B < B) {
+    if (t->xch) (void)hipFree(t->xch);
+    t->xch = nullptr, t->cap_B = 0;
+    TTSX_HIP(hipMalloc(reinterpret_cast<void**>(&t->xch), sizeof(u64) * (size_t)B * X_TEAM));
+    t->cap_B = B;
+  }
+  // tags start at 1: all-zero words match no step
+  TTSX_HIP(hipMemsetAsync(t->xch, 0, sizeof(u64) * (size_t)B * X_TEAM, st));
+  TTSX_HIP(hipMemsetAsync(t->abort_word, 0, sizeof(int), st));
+  TTSX_HIP(hipMemsetAsync(n_steps, 0, sizeof(int32_t) * B, st));
+  TeamP p{};
+  p.img = t->img, p.w2t = t->w2t, p.b2 = t->b2, p.mem_init = t->mem_init, p.att_init = t->att_init;
+  p.rnn_inits = t->rnn_inits, p.loc_conv_t = t->conv_t, p.loc_lin_w = t->loc_lin_w, p.q_bias = t->q_bias, p.v_w = t->v_w;
+  p.stop_w = t->stop_w, p.stop_b = t->stop_b, p.enc = enc, p.annot = annot, p.len = lengths, p.xch = t->xch;
+  p.abort_word = t->abort_word, p.mel = mel, p.align = align, p.stop = stop, p.n_steps = n_steps, p.T = T;
+  p.max_steps = max_decoder_steps;
+  t1_team_kernel<<<B * TEAM, NT, TEAM_LDS, st>>>(p);
+  TTSX_LAUNCH_CHECK();
+  std::vector<int32_t> host(B + 1);
+  TTSX_HIP(hipMemcpyAsync(host.data(), n_steps, sizeof(int32_t) * B, hipMemcpyDeviceToHost, st));
+  TTSX_HIP(hipMemcpyAsync(host.data() + B, t->abort_word, sizeof(int), hipMemcpyDeviceToHost, st));
+  TTSX_HIP(hipStreamSynchronize(st));
+  if (host[B]) {
+    ttsx_set_error("t1_team_run: a workgroup of the decoder team waited too long for its inputs (team not co-resident?)");
+    return TTSX_ERR_STATE;
+  }
+  int run = 0;
+  for (int b = 0; b < B; ++b) run = std::max(run, (int)host[b]);
+  if (steps_run_host) *steps_run_host = run;
+  return TTSX_OK;
+}

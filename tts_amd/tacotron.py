@@ -231,6 +231,11 @@ class Tacotron:
             stop[:, :s].masked_fill_(dead, 0.0)
         return mel[:, :s * r], align[:, :s], stop[:, :s], n_steps
 
+    def set_plan(self, decoder=-1):
+        """Decoder form of the following runs (ttsx_t1_set_plan): -1 by shape, 0 the launch chain, 1 the on-chip
+        team kernel (batch 1-2, T <= 128), 2 one workgroup per utterance."""
+        _lib.check(_lib.load().ttsx_t1_set_plan(self._handle, int(decoder)), "ttsx_t1_set_plan")
+
     @torch.no_grad()
     def postnet(self, mel, n_frames=None):
         """sigmoid(last_linear(PostCBHG(mel))) (models.py:698-699) on [B,F,80].  With `n_frames`
