@@ -23,7 +23,7 @@ enc = m.encode(ids)
 for _ in range(3):
     m.decode(enc)
 torch.cuda.synchronize()
-out = (ctypes.c_longlong * 64)()
+out = (ctypes.c_longlong * 320)()
 lib = _lib.load()
 lib.ttsx_debug_team_timing.restype = ctypes.c_int
 assert lib.ttsx_debug_team_timing(out) == 0
@@ -38,3 +38,9 @@ print("attention workgroup (us relative to the row workgroup's step top):")
 for i, n in enumerate(att):
     print("  %-32s +%.2f  (at %.2f)" % (n, (t[17 + i] - t[16 + i]) / 100.0, (t[17 + i] - t[0]) / 100.0))
 print("  loop top at %.2f" % ((t[16] - t[0]) / 100.0))
+pub = [(t[64 + g] - t[0]) / 100.0 for g in range(32)]
+got = [(t[128 + g] - t[0]) / 100.0 for g in range(32)]
+bar = [(t[192 + g] - t[0]) / 100.0 for g in range(32)]
+print("d1 published by workgroup g at:      " + " ".join("%.2f" % v for v in pub))
+print("d1 + h1 seen by wave 0 of g at:      " + " ".join("%.2f" % v for v in got))
+print("workgroup g past the barrier at:     " + " ".join("%.2f" % v for v in bar))

@@ -73,7 +73,7 @@ constexpr int X_TEAM = NREP * X_REP;    // words per team
 
 struct TeamP {
   const float* img;      // [TG][NS][NT]
-  const float* w2t;      // [256][128] prenet layer 2, transposed (k-major)
+  const float* w2t;      // [64][128][4] prenet layer 2: (k / 4, row, k % 4)
   const float* b2;       // [128]
   const float *mem_init, *att_init, *rnn_inits;
   const float *loc_conv_t /* [62][32] */, *loc_lin_w /* [128][32] */, *q_bias /* [128] query + location-linear bias */, *v_w;
@@ -89,7 +89,11 @@ struct TeamP {
 
 #ifdef TTSX_TEAM_TIMING
 // Tuning build: workgroup 0 / the attention workgroup of utterance 0 leave 100 MHz timestamps of step 50.
-__device__ long long team_marks[64];
+__device__ long long team_marks[64 + 4 * 64];
+#define TEAM_MARK_G(slot)                                                                      \
+  do {                                                                                         \
+    if (b == 0 && t == 50 && threadIdx.x == 0) team_marks[64 + (slot) * 64 + g] = wall_clock64(); \
+  } while (0)
 #define TEAM_MARK(cond, i)                                            \
   do {                                                                \
     if ((cond) && t == 50 && threadIdx.x == 0) team_marks[i] = wall_clock64(); \
@@ -98,19 +102,31 @@ __device__ long long team_marks[64];
 #define TEAM_MARK(cond, i) \
   do {                     \
   } while (0)
+#define TEAM_MARK_G(slot) \
+  do {                    \
+  } while (0)
 #endif
 
 __device__ __forceinline__ void publish(u64* X, int idx, float v, unsigned tag) {
   __hip_atomic_store(X + idx, ((u64)tag << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// A wave-uniform value to word `idx` of all replicas: lanes 0 .. NREP-1 store one replica each.
-__device__ __forceinline__ void publish_all(u64* X, int idx, float v, unsigned tag, int lane) {
-  if (lane < NREP) publish(X + (size_t)lane * X_REP, idx, v, tag);
+// n <= 8 consecutive words (values in LDS) starting at word `first`, to all replicas, by ONE store instruction of
+// the calling wave: lane 8 r + j writes word j of replica r, 8 n contiguous bytes per replica.  Eight waves that
+// each wrote their own word into a line they share with another workgroup measured 2.0 us per exchange against
+// 1.15 for this form (tools/exchange_probe.hip): partial writes of different waves to one line serialise.
+__device__ __forceinline__ void publish_row(u64* X, int first, const float* vals, int n, unsigned tag, int lane) {
+  const int j = lane & 7;
+  if (j < n) publish(X + (size_t)(lane >> 3) * X_REP, first + j, vals[j], tag);
 }
 
 // One word per thread (none where !active; thread 0 of the workgroup may poll a second one): re-read until all
 // words of the wave carry `tag`.  False: aborted (the caller must still reach the barrier that follows).
+// (Keeping two or three reads in flight a fraction of a round trip apart, to see a word sooner, measured slower:
+// 18.6 and 19.1 against 16.4 us per step - more polling reads delay the publishing stores.)
+#ifndef POLL_SLEEP
+#define POLL_SLEEP 1
+#endif
 template <bool SECOND>
 __device__ __forceinline__ bool poll(const u64* a, bool active, const u64* a2, unsigned tag, float* val, float* val2,
                                      int* abort_word) {
@@ -127,7 +143,7 @@ __device__ __forceinline__ bool poll(const u64* a, bool active, const u64* a2, u
       __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       return false;
     }
-    __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_s_sleep(POLL_SLEEP);
   }
 }
 
@@ -192,18 +208,19 @@ __device__ __forceinline__ float gru_new(float sr, float sz, float sni, float sn
 // ------------------------------------------------------------------ a row workgroup
 // LDS of a row workgroup (floats)
 constexpr int RL_W2 = 0, RL_B2 = RL_W2 + PRE0 * PRE1, RL_PART = RL_B2 + PRE1, RL_X1 = RL_PART + 4 * PRE1,
-              RL_HN = RL_X1 + PRE0, RL_FLAG = RL_HN + 8, RL_RING = RL_FLAG + 8, RL_OUT = RL_RING + MEM,
+              RL_HN = RL_X1 + PRE0, RL_PUB = RL_HN + 8, RL_FLAG = RL_PUB + 48, RL_RING = RL_FLAG + 8, RL_OUT = RL_RING + MEM,
               RL_HC = RL_OUT + 192, RL_D1 = RL_HC + 576, RL_D2 = RL_D1 + 512, RL_TOTAL = RL_D2 + 512;
 
 __device__ void row_workgroup(const TeamP& p, int b, int g, float* sm) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int u = 8 * g + wave;  // this wave's hidden unit / prenet row / project_to_decoder_in row
-  float* s_w2 = sm + RL_W2;      // [256][128]
+  float* s_w2 = sm + RL_W2;      // [64][128][4]: (k / 4, row, k % 4)
   float* s_b2 = sm + RL_B2;      // [128]
   float* s_part = sm + RL_PART;  // [4][128]
   float* s_x1 = sm + RL_X1;      // [256]
   float* s_hn = sm + RL_HN;      // [8]
+  float* s_pub = sm + RL_PUB;    // [8] x1 | [8] h1, [8] d1 | [8] h2, [8] d2 | [8] frames: this workgroup's words, gathered
   int* s_flag = reinterpret_cast<int*>(sm + RL_FLAG);
   float* ring = sm + RL_RING;    // [400] memory queue
   float* s_out = sm + RL_OUT;    // [160] frames of the previous step
@@ -240,10 +257,10 @@ __device__ void row_workgroup(const TeamP& p, int b, int g, float* sm) {
     const int cur = t & 1, prv = cur ^ 1;
     TEAM_MARK(b == 0 && g == 0, 0);
     if (t > 0) {
-      // ---- the previous step's frames: into the memory queue; its stop rule
+      // ---- the previous step's frames: into the memory queue
       {
         float v, v2;
-        const bool ok = poll<false>(Xr + X_OUT + prv * X_OUT_N + tid, tid < ODIM, nullptr, tag - 1, &v, &v2, ab);
+        const bool ok = poll<false>(Xr + X_OUT + prv * X_OUT_N + min(tid, ODIM - 1), tid < ODIM, nullptr, tag - 1, &v, &v2, ab);
         if (tid < ODIM) {
           int ph = head + tid;
           ph = ph >= MEM ? ph - MEM : ph;
@@ -255,18 +272,6 @@ __device__ void row_workgroup(const TeamP& p, int b, int g, float* sm) {
         if (*s_flag) return;
       }
       head = head + ODIM >= MEM ? head + ODIM - MEM : head + ODIM;
-      float xo[3], ws[7];
-#pragma unroll
-      for (int j = 0; j < 3; ++j) xo[j] = lane + 64 * j < ODIM ? s_out[lane + 64 * j] : 0.f;
-#pragma unroll
-      for (int j = 0; j < 7; ++j) ws[j] = w[S_STOP + j];
-      float token;
-      const bool done = stop_rule(ws, w[S_B_STOP], xd2, xo, a_last, t, len, p.max_steps, &token);
-      if (g == 0 && wave == 0 && lane == 0) {
-        p.stop[(size_t)b * (p.max_steps + 1) + (t - 1)] = token;
-        if (done) p.n_steps[b] = t;
-      }
-      if (done) return;
     }
     TEAM_MARK(b == 0 && g == 0, 1);
     // ---- prenet layer 1: row u over the memory queue
@@ -281,7 +286,25 @@ __device__ void row_workgroup(const TeamP& p, int b, int g, float* sm) {
         acc += w[S_P1 + j] * xm;
       }
       const float x1 = fmaxf(wsum(acc) + w[S_B_P1], 0.f);
-      publish_all(X + X_X1 + cur * 256, u, x1, tag, lane);
+      if (lane == 0) s_pub[wave] = x1;
+      __syncthreads();
+      if (wave == 0) publish_row(X + X_X1 + cur * 256, 8 * g, s_pub, 8, tag, lane);
+    }
+    if (t > 0) {
+      // ---- the stop rule of the previous step (behind the publication: a team that stops here has published
+      // eight words of a step that does not exist, which nobody reads)
+      float xo[3], ws[7];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) xo[j] = lane + 64 * j < ODIM ? s_out[lane + 64 * j] : 0.f;
+#pragma unroll
+      for (int j = 0; j < 7; ++j) ws[j] = w[S_STOP + j];
+      float token;
+      const bool done = stop_rule(ws, w[S_B_STOP], xd2, xo, a_last, t, len, p.max_steps, &token);
+      if (g == 0 && wave == 0 && lane == 0) {
+        p.stop[(size_t)b * (p.max_steps + 1) + (t - 1)] = token;
+        if (done) p.n_steps[b] = t;
+      }
+      if (done) return;
     }
     TEAM_MARK(b == 0 && g == 0, 2);
     // ---- prenet layer 2, whole, by every workgroup: thread (row, quarter of K)
@@ -289,7 +312,7 @@ __device__ void row_workgroup(const TeamP& p, int b, int g, float* sm) {
     {
       {
         float v, v2;
-        const bool ok = poll<false>(Xr + X_X1 + cur * 256 + tid, tid < PRE0, nullptr, tag, &v, &v2, ab);
+        const bool ok = poll<false>(Xr + X_X1 + cur * 256 + (tid & (PRE0 - 1)), tid < PRE0, nullptr, tag, &v, &v2, ab);
         if (tid < PRE0) s_x1[tid] = v;
         if (!ok) *s_flag = 1;
         __syncthreads();
@@ -297,11 +320,15 @@ __device__ void row_workgroup(const TeamP& p, int b, int g, float* sm) {
       }
       TEAM_MARK(b == 0 && g == 0, 3);
       const int kq = wave >> 1, row = (wave & 1) * 64 + lane;
-      float acc = 0.f;
-      const float* wcol = s_w2 + (size_t)(64 * kq) * PRE1 + row;
-      const float* xs = s_x1 + 64 * kq;
-#pragma unroll 16
-      for (int k = 0; k < 64; ++k) acc += wcol[k * PRE1] * xs[k];
+      const float4* wq = reinterpret_cast<const float4*>(s_w2) + (size_t)(16 * kq) * PRE1 + row;
+      const float4* xq = reinterpret_cast<const float4*>(s_x1 + 64 * kq);
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float4 wv = wq[i * PRE1], xv = xq[i];
+        a0 += wv.x * xv.x, a1 += wv.y * xv.y, a2 += wv.z * xv.z, a3 += wv.w * xv.w;
+      }
+      const float acc = (a0 + a1) + (a2 + a3);
       s_part[kq * PRE1 + row] = acc;
       __syncthreads();
 #pragma unroll
@@ -327,9 +354,9 @@ __device__ void row_workgroup(const TeamP& p, int b, int g, float* sm) {
       sr = wsum(sr) + w[S_B_A], sz = wsum(sz) + w[S_B_A + 1];
       sni = wsum(sni) + w[S_B_A + 2], snh = wsum(snh) + w[S_B_A + 3];
       const float hn = gru_new(sr, sz, sni, snh, pick<4>(hatt, u));
-      publish_all(X + X_HATT + cur * 256, u, hn, tag, lane);
       if (lane == 0) s_hn[wave] = hn;
       __syncthreads();
+      if (wave == 2) publish_row(X + X_HATT + cur * 256, 8 * g, s_hn, 8, tag, lane);
       if (tid < ATT) {
         float q = 0.f;
 #pragma unroll
@@ -368,10 +395,13 @@ __device__ void row_workgroup(const TeamP& p, int b, int g, float* sm) {
       const float d0 = wsum(sd) + w[S_B_1 + 4];
       const float hn = gru_new(sr, sz, sni, snh, pick<4>(h1, u));
       d1_u = hn + d0;
-      publish_all(X + X_H1 + cur * 256, u, hn, tag, lane);
-      publish_all(X + X_D1 + cur * 256, u, d1_u, tag, lane);
+      if (lane == 0) s_pub[8 + wave] = hn, s_pub[16 + wave] = d1_u;
+      __syncthreads();
+      if (wave == 0) publish_row(X + X_D1 + cur * 256, 8 * g, s_pub + 16, 8, tag, lane);
+      if (wave == 1) publish_row(X + X_H1 + cur * 256, 8 * g, s_pub + 8, 8, tag, lane);
     }
     TEAM_MARK(b == 0 && g == 0, 7);
+    TEAM_MARK_G(0);
     // ---- GRU 2 on d1 and h2(t-1); d2 = h2 + d1
     {
       float x[4];
@@ -380,6 +410,7 @@ __device__ void row_workgroup(const TeamP& p, int b, int g, float* sm) {
         const u64* a = tid < RNN ? Xr + X_D1 + cur * 256 + tid : Xr + X_H1 + cur * 256 + (tid - RNN);
         const bool ok = poll<false>(a, true, nullptr, tag, &v, &v2, ab);
         s_d1[tid] = v;
+        TEAM_MARK_G(1);
         if (!ok) *s_flag = 1;
         __syncthreads();
         if (*s_flag) return;
@@ -387,6 +418,7 @@ __device__ void row_workgroup(const TeamP& p, int b, int g, float* sm) {
         for (int j = 0; j < 4; ++j) x[j] = s_d1[lane + 64 * j], h1[j] = s_d1[RNN + lane + 64 * j];
       }
       TEAM_MARK(b == 0 && g == 0, 8);
+      TEAM_MARK_G(2);
       float sr = 0.f, sz = 0.f, sni = 0.f, snh = 0.f;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -397,8 +429,10 @@ __device__ void row_workgroup(const TeamP& p, int b, int g, float* sm) {
       sr = wsum(sr) + w[S_B_2], sz = wsum(sz) + w[S_B_2 + 1];
       sni = wsum(sni) + w[S_B_2 + 2], snh = wsum(snh) + w[S_B_2 + 3];
       const float hn = gru_new(sr, sz, sni, snh, pick<4>(h2, u));
-      publish_all(X + X_H2 + cur * 256, u, hn, tag, lane);
-      publish_all(X + X_D2 + cur * 256, u, hn + d1_u, tag, lane);
+      if (lane == 0) s_pub[24 + wave] = hn, s_pub[32 + wave] = hn + d1_u;
+      __syncthreads();
+      if (wave == 0) publish_row(X + X_D2 + cur * 256, 8 * g, s_pub + 32, 8, tag, lane);
+      if (wave == 1) publish_row(X + X_H2 + cur * 256, 8 * g, s_pub + 24, 8, tag, lane);
     }
     TEAM_MARK(b == 0 && g == 0, 9);
     // ---- frames: row 5g + wave of proj_to_mel (waves 0..4), sigmoid
@@ -414,14 +448,17 @@ __device__ void row_workgroup(const TeamP& p, int b, int g, float* sm) {
       for (int j = 0; j < 4; ++j) xd2[j] = s_d2[lane + 64 * j], h2[j] = s_d2[RNN + lane + 64 * j];
     }
     TEAM_MARK(b == 0 && g == 0, 10);
-    if (wave < 5) {
+    {
       float acc = 0.f;
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc += w[S_MEL + j] * xd2[j];
       const float o = sigmoidf_(wsum(acc) + w[S_B_MEL]);
-      const int row = 5 * g + wave;
-      publish_all(X + X_OUT + cur * X_OUT_N, row, o, tag, lane);
-      if (lane == 0) p.mel[((size_t)b * (p.max_steps + 1) + t) * ODIM + row] = o;
+      if (wave < 5 && lane == 0) s_pub[40 + wave] = o;
+      __syncthreads();
+      if (wave == 0) {
+        publish_row(X + X_OUT + cur * X_OUT_N, 5 * g, s_pub + 40, 5, tag, lane);
+        if (lane < 5) p.mel[((size_t)b * (p.max_steps + 1) + t) * ODIM + 5 * g + lane] = s_pub[40 + lane];
+      }
     }
     TEAM_MARK(b == 0 && g == 0, 11);
   }
@@ -435,11 +472,10 @@ __device__ void attention_workgroup(const TeamP& p, int b, float* sm) {
   float* s_wl = sm;                                  // [62][32] location conv, filter fastest
   float* s_wld = s_wl + 2 * LOCK * LOCF;             // [128][32] location linear layer
   float* s_v = s_wld + ATT * LOCF;                   // [128]
-  float* s_qb = s_v + ATT;                           // [128] query bias + location-linear bias
-  float* s_a = s_qb + ATT;                           // [2][TMAX + 32] previous / cumulative alignment, 15 zeros in front
+  float* s_a = s_v + 2 * ATT;                           // [2][TMAX + 32] previous / cumulative alignment, 15 zeros in front
   float* s_cf = s_a + 2 * (TMAX + 32);               // [TMAX][33]
-  float* s_qp = s_cf + TMAX * (LOCF + 1);            // [4][128]
-  float* s_ep = s_qp + 4 * ATT;                      // [4][TMAX]
+  float* s_q = s_cf + TMAX * (LOCF + 1);             // [4][128] partial sums of the query (+ biases in the first)
+  float* s_ep = s_q + 4 * ATT;                      // [4][TMAX]
   float* s_al = s_ep + 4 * TMAX;                     // [TMAX]
   float* s_cp = s_al + TMAX;                         // [2][256]
   float* s_red = s_cp + 2 * ENC;                     // [8]
@@ -452,7 +488,8 @@ __device__ void attention_workgroup(const TeamP& p, int b, float* sm) {
 
   for (int i = tid; i < 2 * LOCK * LOCF; i += NT) s_wl[i] = p.loc_conv_t[i];
   for (int i = tid; i < ATT * LOCF; i += NT) s_wld[i] = p.loc_lin_w[i];
-  if (tid < ATT) s_v[tid] = p.v_w[tid], s_qb[tid] = p.q_bias[tid];
+  if (tid < ATT) s_v[tid] = p.v_w[tid];
+  const float qb_d = p.q_bias[tid & (ATT - 1)];  // query bias + location-linear bias
   for (int i = tid; i < 2 * (TMAX + 32); i += NT) s_a[i] = 0.f;
   if (tid == 0) *s_flag = 0;
   // energy role: position pos, attention dims 32 dq .. 32 dq + 31 (a wave has one dq: the weights it reads from
@@ -461,8 +498,6 @@ __device__ void attention_workgroup(const TeamP& p, int b, float* sm) {
   float pa[32];
 #pragma unroll
   for (int i = 0; i < 32; ++i) pa[i] = pos < len ? annot[(size_t)pos * ATT + 32 * dq + i] : 0.f;
-  // query role: dim d, shares 8 tg .. 8 tg + 7
-  const int d = tid & (ATT - 1), tg = tid >> 7;
   // context role: column c, positions 64 th .. 64 th + 63
   const int c = tid & (ENC - 1), th = tid >> 8;
   float er[64];
@@ -527,23 +562,20 @@ __device__ void attention_workgroup(const TeamP& p, int b, float* sm) {
     const unsigned tag = (unsigned)t + 1u;
     const int cur = t & 1;
     TEAM_MARK(b == 0, 17);
-    // ---- query = sum of the 32 shares: thread (d, tg) adds 8 of them (every word is read by this thread only)
+    // ---- query = sum of the 32 shares (+ biases): thread (d, tg) reads 8 words, all of them in every round (a
+    // read inside a branch would wait for its own round trip); the four partial sums meet in the energies
     {
+      const int d = tid & (ATT - 1), tg = tid >> 7;
       const u64* Q = X + X_QS + cur * X_QS_N + (size_t)(8 * tg) * ATT + d;
-      float acc = 0.f;
-      bool got[8] = {false, false, false, false, false, false, false, false};
       float val[8];
       bool fail = false;
       for (long spin = 0;; ++spin) {
         bool ok = true;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          if (!got[j]) {
-            const u64 v = __hip_atomic_load(Q + (size_t)j * ATT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            got[j] = (unsigned)(v >> 32) == tag;
-            val[j] = __uint_as_float((unsigned)v);
-          }
-          ok = ok && got[j];
+          const u64 v = __hip_atomic_load(Q + (size_t)j * ATT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok = ok && (unsigned)(v >> 32) == tag;
+          val[j] = __uint_as_float((unsigned)v);
         }
         if (__all(ok)) break;
         if ((spin & 127) == 127 && __hip_atomic_load(ab, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) fail = true;
@@ -554,9 +586,8 @@ __device__ void attention_workgroup(const TeamP& p, int b, float* sm) {
         if (fail) break;
         __builtin_amdgcn_s_sleep(1);
       }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) acc += val[j];
-      s_qp[tg * ATT + d] = acc;
+      s_q[tg * ATT + d] = (((val[0] + val[1]) + (val[2] + val[3])) + ((val[4] + val[5]) + (val[6] + val[7]))) +
+                          (tg == 0 ? qb_d : 0.f);
       if (fail) *s_flag = 1;
     }
     __syncthreads();
@@ -564,13 +595,18 @@ __device__ void attention_workgroup(const TeamP& p, int b, float* sm) {
     TEAM_MARK(b == 0, 18);
     // ---- energies: e[pos] = sum_d v[d] tanh(q[d] + annot[pos][d] + (W_ld cf[pos])[d])
     {
-      float e = 0.f;
+      const float4* q4 = reinterpret_cast<const float4*>(s_q + 32 * dq);
+      const float4* v4 = reinterpret_cast<const float4*>(s_v + 32 * dq);
+      float e0 = 0.f, e1 = 0.f;
 #pragma unroll
-      for (int i = 0; i < 32; ++i) {
-        const int dd = 32 * dq + i;
-        const float q = ((s_qp[dd] + s_qp[ATT + dd]) + (s_qp[2 * ATT + dd] + s_qp[3 * ATT + dd])) + s_qb[dd];
-        e += s_v[dd] * fast_tanhf(q + pl[i]);
+      for (int i = 0; i < 8; ++i) {
+        const float4 qa = q4[i], qb = q4[ATT / 4 + i], qc = q4[2 * ATT / 4 + i], qd = q4[3 * ATT / 4 + i], v = v4[i];
+        const float4 q = make_float4((qa.x + qb.x) + (qc.x + qd.x), (qa.y + qb.y) + (qc.y + qd.y),
+                                     (qa.z + qb.z) + (qc.z + qd.z), (qa.w + qb.w) + (qc.w + qd.w));
+        e0 += v.x * fast_tanhf(q.x + pl[4 * i]) + v.z * fast_tanhf(q.z + pl[4 * i + 2]);
+        e1 += v.y * fast_tanhf(q.y + pl[4 * i + 1]) + v.w * fast_tanhf(q.w + pl[4 * i + 3]);
       }
+      const float e = e0 + e1;
       s_ep[dq * TMAX + pos] = e;
     }
     __syncthreads();
@@ -618,7 +654,7 @@ __device__ void attention_workgroup(const TeamP& p, int b, float* sm) {
     // ---- the stop rule of this step, as every row workgroup evaluates it
     {
       float v, v2;
-      const u64* a = tid < RNN ? X + X_D2 + cur * 256 + tid : X + X_OUT + cur * X_OUT_N + (tid - RNN);
+      const u64* a = tid < RNN ? X + X_D2 + cur * 256 + tid : X + X_OUT + cur * X_OUT_N + min(tid - RNN, ODIM - 1);
       const bool ok = poll<false>(a, tid < RNN + ODIM, nullptr, tag, &v, &v2, ab);
       s_st[tid] = v;
       if (!ok) *s_flag = 1;
@@ -682,8 +718,8 @@ __device__ __forceinline__ float at(const float* W, int row, int K, int lane, in
 __global__ void pack_team_kernel(PackP p) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < (size_t)PRE0 * PRE1) {
-    const int k = (int)(i / PRE1), r = (int)(i % PRE1);
-    p.w2t[i] = p.w.pre_w1[(size_t)r * PRE0 + k];
+    const int kk = (int)(i & 3), r = (int)((i >> 2) % PRE1), k4 = (int)(i / (4 * PRE1));
+    p.w2t[i] = p.w.pre_w1[(size_t)r * PRE0 + 4 * k4 + kk];
   }
   if (i < ATT) p.q_bias[i] = p.w.query_b[i] + p.w.loc_lin_b[i];
   if (i < LOCF * 2 * LOCK) p.conv_t[(i % (2 * LOCK)) * LOCF + i / (2 * LOCK)] = p.w.loc_conv_w[i];
@@ -789,7 +825,7 @@ void t1_team_destroy(t1_team* t) {
 
 #ifdef TTSX_TEAM_TIMING
 extern "C" int ttsx_debug_team_timing(long long* out) {
-  return hipMemcpyFromSymbol(out, HIP_SYMBOL(team_marks), sizeof(long long) * 64) == hipSuccess ? 0 : -1;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(team_marks), sizeof(long long) * (64 + 4 * 64)) == hipSuccess ? 0 : -1;
 }
 #endif
 
@@ -803,7 +839,11 @@ int t1_team_run(t1_team* t, const float* enc, const float* annot, const int32_t*
   if (t->cap_B < B) {
     if (t->xch) (void)hipFree(t->xch);
     t->xch = nullptr, t->cap_B = 0;
+#ifdef TEAM_XCH_FINE
+    TTSX_HIP(hipExtMallocWithFlags(reinterpret_cast<void**>(&t->xch), sizeof(u64) * (size_t)B * X_TEAM, hipDeviceMallocFinegrained));
+#else
     TTSX_HIP(hipMalloc(reinterpret_cast<void**>(&t->xch), sizeof(u64) * (size_t)B * X_TEAM));
+#endif
     t->cap_B = B;
   }
   // tags start at 1: all-zero words match no step
