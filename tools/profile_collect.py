@@ -22,7 +22,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
 dec_steps = int(sys.argv[2]) if len(sys.argv) > 2 else 384
 src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
-dst = os.path.join(ROOT, "profiles")
+dst = os.environ.get("PROFILE_DST", os.path.join(ROOT, "profiles"))
+os.makedirs(dst, exist_ok=True)
 
 
 def short(name):
