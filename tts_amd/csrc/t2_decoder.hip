@@ -53,6 +53,7 @@
 #include <vector>
 
 #include "common.h"
+#include "t2_team.h"
 
 namespace {
 
@@ -1572,6 +1573,10 @@ struct ttsx_t2_decoder {
   int poll_chunk, poll_ahead;  // free run at batch 1-2: steps per graph and steps kept in flight (0: defaults)
   int plan_fused, plan_split, plan_share_q;  // ttsx_t2_decoder_set_plan: -1 by shape (default), 0 off, 1 on
   bool share_q;  // three-launch attention without the query launch: the energies op adds up the query shares
+  // one utterance, short text, plain attention: the whole run as one persistent launch with the weights on chip
+  t2_team* team;
+  int plan_team;      // ttsx_t2_decoder_set_team: -1 by shape (default), 0 never, 1 wherever the shapes allow
+  bool team_gave_up;  // a team run timed out waiting for its workgroups: the default plan stays with the launch chain
 };
 
 namespace {
@@ -1724,6 +1729,7 @@ int ensure_proj(ttsx_t2_decoder* d, int r, hipStream_t st) {
   TTSX_HIP(hipMemcpyAsync(all_b, d->proj_b_src, sizeof(float) * kept, hipMemcpyDeviceToDevice, st));
   TTSX_HIP(hipMemcpyAsync(all_b + kept, ext_b, sizeof(float) * ext_rows, hipMemcpyDeviceToDevice, st));
   int rc = pack_layer(&d->w_proj, &d->b_proj, all_w, K, nullptr, 0, all_b, nullptr, rows, 0, st);
+  if (!rc && d->team) rc = t2_team_set_proj(d->team, all_w, all_b, r, st);
   TTSX_HIP(hipStreamSynchronize(st));
   (void)hipFree(ext_w), (void)hipFree(ext_b), (void)hipFree(all_w), (void)hipFree(all_b);
   if (rc) return rc;
@@ -2158,7 +2164,7 @@ extern "C" int ttsx_t2_decoder_create(const ttsx_t2_decoder_weights* w, int r_in
   ScopeExit on_fail([&] { (void)ttsx_t2_decoder_destroy(d); });
   ScopeExit free_tmp([&] { (void)hipFree(w_ih2), (void)hipFree(a2f), (void)hipFree(b2f); });
   d->r_init = r_init, d->norm = attn_norm, d->odim = MEL_DIM * r_init;
-  d->plan_fused = d->plan_split = d->plan_share_q = -1;
+  d->plan_fused = d->plan_split = d->plan_share_q = d->plan_team = -1;
   int rc = 0;
   rc |= pack_layer(&d->w_lstm1, &d->b_lstm1, w->attn_rnn_w_ih, PRENET_DIM + ENC_DIM, w->attn_rnn_w_hh, QUERY_DIM,
                    w->attn_rnn_b_ih, w->attn_rnn_b_hh, 4 * QUERY_DIM, QUERY_DIM, st);
@@ -2186,6 +2192,16 @@ extern "C" int ttsx_t2_decoder_create(const ttsx_t2_decoder_weights* w, int r_in
       w->prenet_bn_var[1], PRENET_DIM, PRENET_DIM);
   TTSX_LAUNCH_CHECK();
   rc |= pack_layer(&d->w_pre2, &d->b_pre2, a2f, PRENET_DIM, nullptr, 0, b2f, nullptr, PRENET_DIM, 0, st);
+  {
+    T2TeamWeights tw{};
+    tw.attn_w_ih = w->attn_rnn_w_ih, tw.attn_w_hh = w->attn_rnn_w_hh, tw.attn_b_ih = w->attn_rnn_b_ih;
+    tw.attn_b_hh = w->attn_rnn_b_hh, tw.dec_w_ih = w->dec_rnn_w_ih, tw.dec_w_hh = w->dec_rnn_w_hh;
+    tw.dec_b_ih = w->dec_rnn_b_ih, tw.dec_b_hh = w->dec_rnn_b_hh, tw.query_w = w->query_w, tw.v_w = w->v_w;
+    tw.v_b = w->v_b, tw.loc_conv_w = w->loc_conv_w, tw.loc_dense_w = w->loc_dense_w;
+    tw.a2f = a2f, tw.b2f = b2f, tw.b1f = d->b1f;
+    const int trc = t2_team_create(&tw, st, &d->team);
+    if (trc) return trc;
+  }
   rc |= copy_dev(&d->proj_w_src, w->proj_w, (size_t)d->odim * (DEC_DIM + ENC_DIM), st);
   rc |= copy_dev(&d->proj_b_src, w->proj_b, d->odim, st);
   rc |= copy_dev(&d->stop_w_src, w->stop_w, DEC_DIM + d->odim, st);
@@ -2234,6 +2250,7 @@ extern "C" int ttsx_t2_decoder_create(const ttsx_t2_decoder_weights* w, int r_in
 extern "C" int ttsx_t2_decoder_destroy(ttsx_t2_decoder* d) {
   if (!d) return TTSX_OK;
   free_workspace(d);
+  t2_team_destroy(d->team);
   float* bufs[] = {d->w_lstm1, d->b_lstm1, d->w_lstm2, d->b_lstm2, d->w_query, d->b_query,
                    d->w_pre2,  d->b_pre2,  d->w_proj,  d->b_proj,  d->proj_w_src, d->proj_b_src, d->stop_w_src,
                    d->stop_b_src, d->a1f, d->b1f, d->inputs_w, d->v_w, d->v_b, d->loc_conv_w, d->loc_dense_w,
@@ -2493,9 +2510,33 @@ extern "C" int ttsx_t2_decoder_run(ttsx_t2_decoder* d, const float* enc, const i
   hipStream_t st = static_cast<hipStream_t>(stream);
   int rc = ensure_proj(d, r, st);
   if (rc) return rc;
+  const bool carried = d->keep_next || d->mem0_set;  // state or a first frame handed over by set_initial
   rc = ttsx_t2_decoder_begin(d, enc, enc_len, B, T, stream);
   if (rc) return rc;
   TTSX_HIP(hipMemsetAsync(n_steps, 0, sizeof(int32_t) * B, st));
+  // One utterance of up to 128 symbols with the plain location-sensitive attention: the whole run is one
+  // persistent launch of a 216-workgroup team that keeps every weight in registers and LDS (t2_team.hip).
+  if (t2_team_supports(d->team, B, T, r) && !carried && !d->variant && d->graves_K == 0 &&
+      (d->plan_team == 1 || (d->plan_team == -1 && !d->team_gave_up))) {
+    T2TeamState so{};
+    so.h_a = d->h_a[0], so.h_a_alt = d->h_a[1], so.c_a = d->c_a, so.h_d = d->h_d[0], so.h_d_alt = d->h_d[1];
+    so.c_d = d->c_d, so.ctx = d->ctx, so.x1 = d->x1;
+    int run = 0;
+    rc = t2_team_run(d->team, d->enc_ws, d->P, d->len_ws, T, r, max_steps, stop_threshold, fixed_steps, d->norm, mel,
+                     align, stop, n_steps, &so, &run, st);
+    if (rc == TTSX_OK) {
+      if (steps_run_host) *steps_run_host = run;
+      d->last_launched = run, d->steps_done = run, d->begun = false;
+      return TTSX_OK;
+    }
+    // TTSX_ERR_STATE: the team did not become resident together and its bounded waits gave up.  Under the default
+    // plan the handle then stays with the launch chain, which starts over from a fresh state.
+    if (rc != TTSX_ERR_STATE || d->plan_team == 1) return rc;
+    d->team_gave_up = true;
+    rc = ttsx_t2_decoder_begin(d, enc, enc_len, B, T, stream);
+    if (rc) return rc;
+    TTSX_HIP(hipMemsetAsync(n_steps, 0, sizeof(int32_t) * B, st));
+  }
   RunCtx* h = d->rc_host;
   h->r = r, h->free_running = fixed_steps ? 0 : 1, h->threshold = stop_threshold;
   h->mel = mel, h->mel_rows = max_steps * r, h->align = align, h->align_rows = max_steps;
@@ -2554,6 +2595,13 @@ extern "C" int ttsx_t2_decoder_set_plan(ttsx_t2_decoder* d, int fused_attention,
   for (int v : {fused_attention, split_lstm, share_query})
     TTSX_ARG(v >= -1 && v <= 1, "ttsx_t2_decoder_set_plan: %d is not -1 (by shape), 0 (off) or 1 (on)", v);
   d->plan_fused = fused_attention, d->plan_split = split_lstm, d->plan_share_q = share_query;
+  return TTSX_OK;
+}
+
+extern "C" int ttsx_t2_decoder_set_team(ttsx_t2_decoder* d, int team) {
+  TTSX_ARG(d, "ttsx_t2_decoder_set_team: null handle");
+  TTSX_ARG(team >= -1 && team <= 1, "ttsx_t2_decoder_set_team: %d is not -1 (by shape), 0 (never) or 1 (wherever possible)", team);
+  d->plan_team = team;
   return TTSX_OK;
 }
 

@@ -328,6 +328,11 @@ class Tacotron2:
         _lib.check(_lib.load().ttsx_t2_decoder_set_plan(self._dec_handle, int(fused_attention), int(split_lstm),
                                                         int(share_query)), "ttsx_t2_decoder_set_plan")
 
+    def set_team(self, team=-1):
+        """Whether batch-1 runs may use the persistent team kernel (ttsx_t2_decoder_set_team): -1 by shape, 0 never,
+        1 wherever the shapes allow."""
+        _lib.check(_lib.load().ttsx_t2_decoder_set_team(self._dec_handle, int(team)), "ttsx_t2_decoder_set_team")
+
     def last_steps_launched(self):
         """Decoder steps the last decode() enqueued (at least the steps any utterance needed)."""
         return int(_lib.load().ttsx_t2_decoder_steps_launched(self._dec_handle))
