@@ -463,7 +463,16 @@ def main():
                          "stage_ms": s1, "decoder_us_per_step": d_us,
                          "decoder_hbm_gbs": dec_step_bytes(1, 100) / (d_us * 1e-6) / 1e9,
                          "decoder_hbm_frac": dec_step_bytes(1, 100) / (d_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                         "workload": "B=1, T_in=100, %d decoder steps, r=%d" % (S, r)}
+                         "workload": "B=1, T_in=100, %d decoder steps, r=%d" % (S, r),
+                         "decoder_path": "persistent team kernel: one launch per run, LSTM weights resident in "
+                                         "registers and LDS (decoder_hbm_* price the step at the launch chain's "
+                                         "algorithmic bytes; the weights do not move)"}
+        # the same decode as a chain of launches (what batch 2 and up, and texts beyond 128 symbols, run)
+        model.set_team(0)
+        wl1.run()
+        wl1.run(record=True)
+        out["batch1"]["launch_chain_decoder_us_per_step"] = wl1.stages()["decoder"] * 1e3 / S
+        model.set_team(-1)
         out["batch1_stop_driven"] = batch1_stop_driven(dev, ap)
         import contextlib
         import io
