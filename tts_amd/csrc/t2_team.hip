@@ -35,7 +35,7 @@ typedef unsigned long long u64;
 
 constexpr int NT = 512;
 constexpr int QD = 1024, DD = 1024, ED = 512, PD = 256, AD = 128, MEL = 80;
-constexpr int LOCF = 32, LOCK = 31, LPAD = 15, TMAX = 128;
+constexpr int LOCF = 32, LOCK = 31, LPAD = 15, TMAX = 256;  // (attention roles are built for 128 and for 256 positions)
 constexpr int N_ATT = 64, N_DEC = 128, N_PROJ = 16, N_EN = 4, N_CTX = 4;
 constexpr int G_DEC0 = N_ATT, G_PROJ0 = G_DEC0 + N_DEC, G_EN0 = G_PROJ0 + N_PROJ, G_CTX0 = G_EN0 + N_EN,
               G_TOTAL = G_CTX0 + N_CTX;
@@ -156,24 +156,31 @@ __device__ __forceinline__ float lstm_cell(float gi, float gf, float gg, float g
   return sigmoidf_(go) * tanhf(c_new);
 }
 
-// Alignment weights of the utterance's own positions from the summed energies (threads < TMAX hold one
-// position each): softmax or sigmoid normalisation (OriginalAttention.forward, models.py:343-353).  Called by
-// all threads of the workgroup.  The energy and the context workgroups run exactly this on the same numbers.
+// Alignment weights of the utterance's own positions from the summed energies (threads < TM hold one position
+// each): softmax or sigmoid normalisation (OriginalAttention.forward, models.py:343-353).  Called by all threads
+// of the workgroup.  The energy and the context workgroups run exactly this on the same numbers.
+template <int TM>
 __device__ __forceinline__ float normalise(float e, bool valid, int norm, float* s_red) {
+  constexpr int NW = TM / 64;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const bool softmax = norm == TTSX_NORM_SOFTMAX;
   float m = 0.f;
   if (softmax) {
     const float x = wmax(valid ? e : -INFINITY);
-    if (lane == 0 && wave < 2) s_red[wave] = x;
+    if (lane == 0 && wave < NW) s_red[wave] = x;
     __syncthreads();
-    m = fmaxf(s_red[0], s_red[1]);
+    m = s_red[0];
+#pragma unroll
+    for (int i = 1; i < NW; ++i) m = fmaxf(m, s_red[i]);
   }
   const float v = valid ? (softmax ? expf(e - m) : sigmoidf_(e)) : 0.f;
   const float part = wsum(v);
-  if (lane == 0 && wave < 2) s_red[2 + wave] = part;
+  if (lane == 0 && wave < NW) s_red[4 + wave] = part;
   __syncthreads();
-  return v / (s_red[2] + s_red[3]);
+  float sum = s_red[4];
+#pragma unroll
+  for (int i = 1; i < NW; ++i) sum += s_red[4 + i];
+  return v / sum;
 }
 
 // ------------------------------------------------------------------ attention LSTM: 16 hidden units
@@ -426,21 +433,25 @@ __device__ void proj_role(const T2P& p, int q, float* sm) {
 }
 
 // ------------------------------------------------------------------ energies: 32 attention dimensions
+// TM = positions the role is built for (128 or 256): a thread owns one position and 32 * TM / 512 of the dims.
+template <int TM>
 __device__ void energy_role(const T2P& p, int e, float* sm) {
+  constexpr int NG = NT / TM, ND = 32 / NG;  // position groups of threads; own dims per thread
+  constexpr int CP = TM / 16;                // positions per thread in the location conv
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int T = p.T, len = min(max(p.len[0], 0), T);
   float* s_wl = sm;                              // [62][32] location conv, filter fastest
   float* s_wld = s_wl + 2 * LOCK * LOCF;         // [32 own dims][32]
   float* s_v = s_wld + 32 * LOCF;                // [32]
-  float* s_a = s_v + 32;                         // [2][TMAX + 32] previous / cumulative alignment, 15 zeros in front
-  float* s_cf = s_a + 2 * (TMAX + 32);           // [TMAX][33]
-  float* s_ha = s_cf + TMAX * (LOCF + 1);        // [1024]
+  float* s_a = s_v + 32;                         // [2][TM + 32] previous / cumulative alignment, 15 zeros in front
+  float* s_cf = s_a + 2 * (TM + 32);             // [TM][33]
+  float* s_ha = s_cf + TM * (LOCF + 1);          // [1024]
   float* s_q = s_ha + QD;                        // [32]
-  float* s_ep = s_q + 32;                        // [4][TMAX]
-  float* s_e4 = s_ep + 4 * TMAX;                 // [4][TMAX] partial energies of the four workgroups
-  float* s_red = s_e4 + N_EN * TMAX;             // [4]
-  int* s_flag = reinterpret_cast<int*>(s_red + 4);
+  float* s_ep = s_q + 32;                        // [NG][TM]
+  float* s_e4 = s_ep + NG * TM;                  // [4][TM] partial energies of the four workgroups
+  float* s_red = s_e4 + N_EN * TM;               // [8]
+  int* s_flag = reinterpret_cast<int*>(s_red + 8);
   float wq[NS_EN];
   {
     const float* img = p.img_en + ((size_t)e * NS_EN) * NT + tid;
@@ -450,46 +461,45 @@ __device__ void energy_role(const T2P& p, int e, float* sm) {
   for (int i = tid; i < 2 * LOCK * LOCF; i += NT) s_wl[i] = p.conv_t[i];
   for (int i = tid; i < 32 * LOCF; i += NT) s_wld[i] = p.loc_dense[(size_t)32 * e * LOCF + i];
   if (tid < 32) s_v[tid] = p.v_w[32 * e + tid];
-  for (int i = tid; i < 2 * (TMAX + 32); i += NT) s_a[i] = 0.f;
+  for (int i = tid; i < 2 * (TM + 32); i += NT) s_a[i] = 0.f;
   if (tid == 0) *s_flag = 0;
-  // energy role of a thread: position pos, own dims 8 dq .. 8 dq + 7
-  const int pos = tid & (TMAX - 1), dq = tid >> 7;
-  float pp[8], pl[8];
+  const int pos = tid & (TM - 1), dq = tid / TM;
+  float pp[ND], pl[ND];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) pp[i] = pos < len ? p.P[(size_t)pos * AD + 32 * e + 8 * dq + i] : 0.f;
+  for (int i = 0; i < ND; ++i) pp[i] = pos < len ? p.P[(size_t)pos * AD + 32 * e + ND * dq + i] : 0.f;
   const float vb = p.v_b[0];
   __syncthreads();
-  // location conv, thread (filter f, 8 positions), then the location-dense rows of the own dims:
+  // location conv, thread (filter f, CP positions), then the location-dense rows of the own dims:
   // pl[i] = P[pos][d] + (W_ld . conv features of pos)[d].  Needs the previous alignments only.
   auto location_terms = [&]() {
     {
       const int f = tid & 31, tp = tid >> 5;
-      float acc[8];
+      float acc[CP];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+      for (int i = 0; i < CP; ++i) acc[i] = 0.f;
 #pragma unroll
       for (int ch = 0; ch < 2; ++ch) {
-        const float* a = s_a + ch * (TMAX + 32) + 8 * tp;
-        float win[LOCK + 7];
+        const float* a = s_a + ch * (TM + 32) + CP * tp;
+        float win[LOCK + CP - 1];
 #pragma unroll
-        for (int j = 0; j < LOCK + 7; ++j) win[j] = a[j];
+        for (int j = 0; j < LOCK + CP - 1; ++j) win[j] = a[j];
 #pragma unroll
         for (int j = 0; j < LOCK; ++j) {
           const float wv = s_wl[(ch * LOCK + j) * LOCF + f];
 #pragma unroll
-          for (int i = 0; i < 8; ++i) acc[i] += wv * win[j + i];
+          for (int i = 0; i < CP; ++i) acc[i] += wv * win[j + i];
         }
       }
 #pragma unroll
-      for (int i = 0; i < 8; ++i) s_cf[(8 * tp + i) * (LOCF + 1) + f] = acc[i];
+      for (int i = 0; i < CP; ++i) s_cf[(CP * tp + i) * (LOCF + 1) + f] = acc[i];
     }
     __syncthreads();
     float cf[LOCF];
 #pragma unroll
     for (int f = 0; f < LOCF; ++f) cf[f] = s_cf[pos * (LOCF + 1) + f];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const float4* wl = reinterpret_cast<const float4*>(s_wld + (8 * dq + i) * LOCF);
+    for (int i = 0; i < ND; ++i) {
+      const float4* wl = reinterpret_cast<const float4*>(s_wld + (ND * dq + i) * LOCF);
       float loc = 0.f;
 #pragma unroll
       for (int f4 = 0; f4 < LOCF / 4; ++f4) {
@@ -508,7 +518,7 @@ __device__ void energy_role(const T2P& p, int e, float* sm) {
     const int st = fetch_span<2>(Xc + X_HA, QD, tag, s_ha, p.abort_word, s_flag);
     if (st & 1) return;
     if (st & 2) {
-      if (tid < TMAX) publish(Xc + X_EP, e * TMAX + tid, 0.f, tag | DONE_BIT);
+      if (tid < TM) publish(Xc + X_EP, e * TM + tid, 0.f, tag | DONE_BIT);
       return;
     }
     {
@@ -527,29 +537,33 @@ __device__ void energy_role(const T2P& p, int e, float* sm) {
     __syncthreads();
     // ---- partial energies over the own dims
     {
-      const float4* q4 = reinterpret_cast<const float4*>(s_q + 8 * dq);
-      const float4* v4 = reinterpret_cast<const float4*>(s_v + 8 * dq);
+      const float4* q4 = reinterpret_cast<const float4*>(s_q + ND * dq);
+      const float4* v4 = reinterpret_cast<const float4*>(s_v + ND * dq);
       float e0 = 0.f, e1 = 0.f;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < ND / 4; ++i) {
         const float4 qv = q4[i], v = v4[i];
         e0 += v.x * fast_tanhf(qv.x + pl[4 * i]) + v.z * fast_tanhf(qv.z + pl[4 * i + 2]);
         e1 += v.y * fast_tanhf(qv.y + pl[4 * i + 1]) + v.w * fast_tanhf(qv.w + pl[4 * i + 3]);
       }
-      s_ep[dq * TMAX + pos] = e0 + e1;
+      s_ep[dq * TM + pos] = e0 + e1;
     }
     __syncthreads();
-    if (tid < TMAX)
-      publish(Xc + X_EP, e * TMAX + tid, (s_ep[tid] + s_ep[TMAX + tid]) + (s_ep[2 * TMAX + tid] + s_ep[3 * TMAX + tid]), tag);
+    if (tid < TM) {
+      float ep = s_ep[tid];
+#pragma unroll
+      for (int g = 1; g < NG; ++g) ep += s_ep[g * TM + tid];
+      publish(Xc + X_EP, e * TM + tid, ep, tag);
+    }
     // ---- off the serial chain: this step's alignment (state of the location layer; output row)
-    if (fetch_span<1>(Xc + X_EP, N_EN * TMAX, tag, s_e4, p.abort_word, s_flag) & 1) return;
+    if (fetch_span<N_EN * TM / NT>(Xc + X_EP, N_EN * TM, tag, s_e4, p.abort_word, s_flag) & 1) return;
     {
-      const int i = tid & (TMAX - 1);
-      const float en = ((s_e4[i] + s_e4[TMAX + i]) + (s_e4[2 * TMAX + i] + s_e4[3 * TMAX + i])) + vb;
-      const float a = normalise(en, tid < len, p.norm, s_red);
-      if (tid < TMAX) {
+      const int i = tid & (TM - 1);
+      const float en = ((s_e4[i] + s_e4[TM + i]) + (s_e4[2 * TM + i] + s_e4[3 * TM + i])) + vb;
+      const float a = normalise<TM>(en, tid < len, p.norm, s_red);
+      if (tid < TM) {
         s_a[LPAD + tid] = a;
-        s_a[(TMAX + 32) + LPAD + tid] += a;
+        s_a[(TM + 32) + LPAD + tid] += a;
         if (e == 0 && tid < T) p.align[(size_t)t * T + tid] = a;
       }
     }
@@ -559,19 +573,21 @@ __device__ void energy_role(const T2P& p, int e, float* sm) {
 }
 
 // ------------------------------------------------------------------ context: 128 encoder columns
+template <int TM>
 __device__ void ctx_role(const T2P& p, int c, float* sm) {
+  constexpr int NP = TM / 4;  // positions per thread
   const int tid = threadIdx.x;
   const int T = p.T, len = min(max(p.len[0], 0), T);
-  float* s_e4 = sm;                    // [4][TMAX]
-  float* s_al = s_e4 + N_EN * TMAX;    // [TMAX]
-  float* s_cp = s_al + TMAX;           // [4][128]
-  float* s_red = s_cp + 4 * 128;       // [4]
-  int* s_flag = reinterpret_cast<int*>(s_red + 4);
+  float* s_e4 = sm;                    // [4][TM]
+  float* s_al = s_e4 + N_EN * TM;      // [TM]
+  float* s_cp = s_al + TM;             // [4][128]
+  float* s_red = s_cp + 4 * 128;       // [8]
+  int* s_flag = reinterpret_cast<int*>(s_red + 8);
   const int col = tid & 127, tq = tid >> 7;
-  float er[32];
+  float er[NP];
 #pragma unroll
-  for (int i = 0; i < 32; ++i) {
-    const int ps = 32 * tq + i;
+  for (int i = 0; i < NP; ++i) {
+    const int ps = NP * tq + i;
     er[i] = ps < len ? p.enc[(size_t)ps * ED + 128 * c + col] : 0.f;
   }
   const float vb = p.v_b[0];
@@ -581,21 +597,21 @@ __device__ void ctx_role(const T2P& p, int c, float* sm) {
   for (int t = 0; t < p.S; ++t) {
     const unsigned tag = (unsigned)t + 1u;
     u64* Xc = p.xch + (size_t)(t & 1) * X_PAR;
-    const int st = fetch_span<1>(Xc + X_EP, N_EN * TMAX, tag, s_e4, p.abort_word, s_flag);
+    const int st = fetch_span<N_EN * TM / NT>(Xc + X_EP, N_EN * TM, tag, s_e4, p.abort_word, s_flag);
     if (st & 1) return;
     if (st & 2) break;
     {
-      const int i = tid & (TMAX - 1);
-      const float en = ((s_e4[i] + s_e4[TMAX + i]) + (s_e4[2 * TMAX + i] + s_e4[3 * TMAX + i])) + vb;
-      const float a = normalise(en, tid < len, p.norm, s_red);
-      if (tid < TMAX) s_al[tid] = a;
+      const int i = tid & (TM - 1);
+      const float en = ((s_e4[i] + s_e4[TM + i]) + (s_e4[2 * TM + i] + s_e4[3 * TM + i])) + vb;
+      const float a = normalise<TM>(en, tid < len, p.norm, s_red);
+      if (tid < TM) s_al[tid] = a;
     }
     __syncthreads();
     {
-      const float4* a4 = reinterpret_cast<const float4*>(s_al + 32 * tq);
+      const float4* a4 = reinterpret_cast<const float4*>(s_al + NP * tq);
       float a0 = 0.f, a1 = 0.f;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
+      for (int i = 0; i < NP / 4; ++i) {
         const float4 av = a4[i];
         a0 += av.x * er[4 * i] + av.z * er[4 * i + 2];
         a1 += av.y * er[4 * i + 1] + av.w * er[4 * i + 3];
@@ -611,20 +627,21 @@ __device__ void ctx_role(const T2P& p, int c, float* sm) {
   if (p.st.ctx && tid < 128) p.st.ctx[128 * c + tid] = last;
 }
 
+template <int TM>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void t2_team_kernel(T2P p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int g = blockIdx.x;
   if (g < G_DEC0) att_role(p, g, sm);
   else if (g < G_PROJ0) dec_role(p, g - G_DEC0, sm);
   else if (g < G_EN0) proj_role(p, g - G_PROJ0, sm);
-  else if (g < G_CTX0) energy_role(p, g - G_EN0, sm);
-  else ctx_role(p, g - G_CTX0, sm);
+  else if (g < G_CTX0) energy_role<TM>(p, g - G_EN0, sm);
+  else ctx_role<TM>(p, g - G_CTX0, sm);
 }
 
 constexpr size_t LDS_ATT = (size_t)(LDS_W + PD + QD + ED + 16 + 8) * sizeof(float);
 constexpr size_t LDS_DEC = (size_t)(LDS_W + DD + QD + ED + 8 + 8) * sizeof(float);
 constexpr size_t LDS_EN = (size_t)(2 * LOCK * LOCF + 32 * LOCF + 32 + 2 * (TMAX + 32) + TMAX * (LOCF + 1) + QD + 32 +
-                                   4 * TMAX + N_EN * TMAX + 4 + 8) * sizeof(float);
+                                   4 * TMAX + N_EN * TMAX + 8 + 8) * sizeof(float);
 constexpr size_t TEAM_LDS = LDS_ATT > LDS_DEC ? (LDS_ATT > LDS_EN ? LDS_ATT : LDS_EN) : (LDS_DEC > LDS_EN ? LDS_DEC : LDS_EN);
 
 // ---- packing
@@ -768,8 +785,10 @@ int t2_team_create(const T2TeamWeights* w, hipStream_t st, t2_team** out) {
                 "pack_lstm_kernel's grid covers every image");
   pack_lstm_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(pp);
   TTSX_LAUNCH_CHECK();
-  TTSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(t2_team_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)TEAM_LDS));
+  TTSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(t2_team_kernel<128>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)TEAM_LDS));
+  TTSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(t2_team_kernel<256>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)TEAM_LDS));
   TTSX_HIP(hipStreamSynchronize(st));
   on_fail.dismiss();
   *out = t;
@@ -820,8 +839,10 @@ int t2_team_run(t2_team* t, const float* enc, const float* P, const int32_t* len
   p.T = T, p.r = r, p.S = max_steps, p.free_run = fixed_steps ? 0 : 1, p.norm = norm, p.thr = stop_threshold;
   void* args[] = {&p};
   // cooperative: the launch is refused, not hung, if 216 workgroups of this size cannot be resident together
-  TTSX_HIP(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(t2_team_kernel), dim3(G_TOTAL), dim3(NT), args,
-                                      (unsigned)TEAM_LDS, st));
+  // (the attention roles are built for 128 and for 256 positions: a thread owns one position either way)
+  const void* kernel = T <= 128 ? reinterpret_cast<const void*>(t2_team_kernel<128>)
+                                : reinterpret_cast<const void*>(t2_team_kernel<256>);
+  TTSX_HIP(hipLaunchCooperativeKernel(kernel, dim3(G_TOTAL), dim3(NT), args, (unsigned)TEAM_LDS, st));
   int32_t host[2] = {0, 0};
   TTSX_HIP(hipMemcpyAsync(&host[0], n_steps, sizeof(int32_t), hipMemcpyDeviceToHost, st));
   TTSX_HIP(hipMemcpyAsync(&host[1], t->abort_word, sizeof(int), hipMemcpyDeviceToHost, st));
