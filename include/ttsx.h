@@ -152,6 +152,12 @@ int ttsx_t2_decoder_run(ttsx_t2_decoder* dec, const float* enc, const int32_t* e
  * the shapes allow.  For A/B timing and for tests that hold the alternatives against each other. */
 int ttsx_t2_decoder_set_plan(ttsx_t2_decoder* dec, int fused_attention, int split_lstm, int share_query);
 
+/* Batches on the MFMA engine (B > 2): prenet layer 2 of a step inside the projection launch of the step before it
+ * (its workgroups wait for flags that the projection's row blocks raise: one launch boundary less per step).
+ * No reference counterpart.  -1 where it measured faster (padded batch 64 with the early / late LSTM split), 0 never,
+ * 1 on every batch above 2; the results are bit-equal either way. */
+int ttsx_t2_decoder_set_fusion(ttsx_t2_decoder* dec, int prenet_in_projection);
+
 /* Whether a run of one or two utterances may use the persistent team kernel (no reference counterpart): texts of up to
  * 256 symbols, reduction factor 1-2, plain location-sensitive attention, no state carried over by
  * ttsx_t2_decoder_set_initial.  One launch decodes a whole utterance (two utterances: two launches) with all decoder weights held in the

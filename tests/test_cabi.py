@@ -70,6 +70,7 @@ def test_entry_points_reject_bad_arguments_before_any_device_call():
                                                                one, byref(n), None),
         "ttsx_t2_decoder_set_plan": lambda: lib.ttsx_t2_decoder_set_plan(None, -1, -1, -1),
         "ttsx_t2_decoder_set_team": lambda: lib.ttsx_t2_decoder_set_team(None, -1),
+        "ttsx_t2_decoder_set_fusion": lambda: lib.ttsx_t2_decoder_set_fusion(None, -1),
         "ttsx_t2_decoder_set_polling": lambda: lib.ttsx_t2_decoder_set_polling(None, 0, 0),
         "ttsx_t2_decoder_steps_launched": lambda: lib.ttsx_t2_decoder_steps_launched(None),
         "ttsx_t2_decoder_begin": lambda: lib.ttsx_t2_decoder_begin(None, one, None, 1, 8, None),

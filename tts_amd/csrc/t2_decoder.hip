@@ -76,6 +76,7 @@ struct RunCtx {
   // stream synchronisation, no copy): [0] every utterance has ended, [1] steps completed (written by the last
   // node of every chunk).  Null: not reported.
   int* host_words;
+  int sync_failed;  // a workgroup that waits for other workgroups of its own launch gave up (see Prenet2AfterProjOp)
 };
 
 // A step's launches do their arithmetic but keep nothing once every utterance has ended.  The test compares the
@@ -235,6 +236,9 @@ struct GemmP {
   float* out[2];  // LINEAR/PROJ: out[0] quad layout; LSTM: h ping-pong pair, written at parity^1
   float* c;       // LSTM cell state, quad layout
   float* x1;      // PROJ: prenet layer-1 activations for the next step, quad layout
+  // PROJ with prenet layer 2 of the next step in the same launch (Prenet2AfterProjOp): x1 leaves through
+  // cache-bypassing stores and the row block then raises x1_flags[column tile * 16 + block] to the step's tag
+  unsigned* x1_flags;
   // GRU (Tacotron v1; rows of a hidden unit = r, z, n_input, n_hidden over K = [x; h]): h ping-pong in
   // `out` like the LSTM; with `resid` the launch also writes sum_out = h_new + resid (residual GRU stack)
   const float* resid;
@@ -363,8 +367,17 @@ __device__ __forceinline__ float epilogue_quad(const GemmP& p, int quad, int b, 
       }
     } else {
       const int xq = quad - p.o_quads - 4;
-      reinterpret_cast<float4*>(p.x1)[(size_t)xq * Bpad + b] =
-          make_float4(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f));
+      const float4 x = make_float4(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f));
+      if (p.x1_flags) {
+        // read by other workgroups of this launch: past the (per-XCD, not mutually coherent) L2
+        unsigned long long* dst = reinterpret_cast<unsigned long long*>(p.x1) + ((size_t)xq * Bpad + b) * 2;
+        __hip_atomic_store(dst, ((unsigned long long)__float_as_uint(x.y) << 32) | __float_as_uint(x.x), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(dst + 1, ((unsigned long long)__float_as_uint(x.w) << 32) | __float_as_uint(x.z),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        reinterpret_cast<float4*>(p.x1)[(size_t)xq * Bpad + b] = x;
+      }
     }
   }
   return 0.f;
@@ -512,6 +525,16 @@ struct GemmOp {
       if (MODE == MODE_LSTM || MODE == MODE_GRU) s_h[(t / NT) * 4 + (lane >> 4)][(t % NT) * 16 + (lane & 15)] = h;
     }
     if (KGW == 20) FA_MARK(11);
+    if (MODE == MODE_PROJ && R == 1 && NT == 1 && p.x1_flags) {
+      // (one tile per workgroup: wave 0 alone has written it) the stores have reached memory, then the flag
+      const int xb = rb - (p.o_quads / 4 + 1);
+      if (xb >= 0 && wave == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0)
+          __hip_atomic_store(p.x1_flags + (b0 / 16) * (PRENET_DIM / 16) + xb,
+                             (unsigned)(p.ctx->base + p.step_in_chunk + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
     if (qshare) {
       __syncthreads();
       const int d = threadIdx.x & (ATT_DIM - 1), c0 = (threadIdx.x >> 7) * QC;
@@ -637,6 +660,83 @@ template <class A, class B>
 __global__ __launch_bounds__(GEMM_THREADS) void dual_kernel(typename A::P pa, typename B::P pb, int n_first) {
   if ((int)blockIdx.x < n_first) A::run(pa, blockIdx.x);
   else B::run(pb, blockIdx.x - n_first);
+}
+
+// Prenet layer 2 of the NEXT step inside the projection launch of this one (MFMA engine): one launch boundary
+// less per step.  Workgroup (row block rb2 of 16, column tile ct) waits until the 16 projection workgroups that
+// produce prenet layer 1 for its 16 utterances have raised their flags to this step's tag, then wave 0 reads the
+// x1 tile past the L2 (the producers may sit on other XCDs), multiplies (64 MFMAs) and writes x2 for the next
+// launch.  The projection workgroups have the lower block indices, so they are resident before a waiting
+// workgroup can occupy a slot; the wait is bounded all the same.
+struct Prenet2AfterProjOp {
+  typedef GemmP P;  // Wp / bias: prenet layer 2; seg[0].x[0]: x1; out[0]: x2; x1_flags; ctx, step_in_chunk of THIS step
+  static __device__ __forceinline__ void run(const GemmP& p, int wg) {
+    if (threadIdx.x >= 64) return;
+    RunCtx* cx = p.ctx;
+    if (step_done(cx, p.step_in_chunk)) return;  // (the producers skip their epilogue under the same test)
+    const int lane = threadIdx.x;
+    constexpr int NRB = PRENET_DIM / 16, KG = PRENET_DIM / 16;
+    const int rb = wg % NRB, ct = wg / NRB, b0 = ct * 16;
+    const unsigned tag = (unsigned)(cx->base + p.step_in_chunk + 1);
+    const float4* W = reinterpret_cast<const float4*>(p.Wp) + (size_t)rb * KG * 64 + lane;
+    float4 wv[KG];
+#pragma unroll
+    for (int i = 0; i < KG; ++i) wv[i] = W[(size_t)i * 64];
+    const float4 bias = reinterpret_cast<const float4*>(p.bias)[rb * 4 + (lane >> 4)];
+    bool ok = false;
+    for (long spin = 0; spin < 4000000; ++spin) {
+      const unsigned f = lane < NRB ? __hip_atomic_load(p.x1_flags + ct * NRB + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : tag;
+      if (__all(f == tag)) {
+        ok = true;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    if (!ok) {
+      if (lane == 0) cx->sync_failed = 1;
+      return;
+    }
+    // B fragments: lane l holds x1[16 kg + 4 (l >> 4) + s][b0 + (l & 15)], s = 0..3 (one quad of the quad layout)
+    const unsigned long long* X = reinterpret_cast<const unsigned long long*>(p.seg[0].x[0]) +
+                                  ((size_t)(lane >> 4) * p.Bpad + b0 + (lane & 15)) * 2;
+    unsigned long long xr[KG][2];
+#pragma unroll
+    for (int i = 0; i < KG; ++i) {
+      xr[i][0] = __hip_atomic_load(X + (size_t)i * 4 * p.Bpad * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      xr[i][1] = __hip_atomic_load(X + (size_t)i * 4 * p.Bpad * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // The sums are formed in the order of the launch this replaces (GemmOp<1, 1, 2, MODE_LINEAR>: wave w adds
+    // k-groups w and w + 8, the eight partial tiles are added in wave order, then the bias), so that the two
+    // ways to run a step agree bit for bit.
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < GEMM_WAVES; ++w) {
+      f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < KG / GEMM_WAVES; ++i) {
+        const int kg = w + GEMM_WAVES * i;
+        a = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[kg].x, __uint_as_float((unsigned)xr[kg][0]), a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[kg].y, __uint_as_float((unsigned)(xr[kg][0] >> 32)), a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[kg].z, __uint_as_float((unsigned)xr[kg][1]), a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[kg].w, __uint_as_float((unsigned)(xr[kg][1] >> 32)), a, 0, 0, 0);
+      }
+      if (w == 0) v = a;
+      else v += a;
+    }
+    v[0] += bias.x, v[1] += bias.y, v[2] += bias.z, v[3] += bias.w;
+    const float4 o = make_float4(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f));
+    reinterpret_cast<float4*>(p.out[0])[(size_t)(rb * 4 + (lane >> 4)) * p.Bpad + b0 + (lane & 15)] = o;
+  }
+};
+
+// Workgroups [0, na) run op A, [na, na + nc) op C, the rest op B.
+template <class A, class C, class B>
+__global__ __launch_bounds__(GEMM_THREADS) void triple_kernel(typename A::P pa, typename C::P pc, typename B::P pb, int na,
+                                                              int nc) {
+  const int wg = blockIdx.x;
+  if (wg < na) A::run(pa, wg);
+  else if (wg < na + nc) C::run(pc, wg - na);
+  else B::run(pb, wg - na - nc);
 }
 
 // ------------------------------------------------------------------ attention
@@ -1573,6 +1673,8 @@ struct ttsx_t2_decoder {
   int poll_chunk, poll_ahead;  // free run at batch 1-2: steps per graph and steps kept in flight (0: defaults)
   int plan_fused, plan_split, plan_share_q;  // ttsx_t2_decoder_set_plan: -1 by shape (default), 0 off, 1 on
   bool share_q;  // three-launch attention without the query launch: the energies op adds up the query shares
+  unsigned* x1_flags;  // [Bpad / 16][16] step tags of the prenet layer-1 row blocks (Prenet2AfterProjOp)
+  int plan_fuse_p2;    // ttsx_t2_decoder_set_fusion: prenet layer 2 of the next step inside the projection launch
   // one utterance, short text, plain attention: the whole run as one persistent launch with the weights on chip
   t2_team* team;
   int plan_team;      // ttsx_t2_decoder_set_team: -1 by shape (default), 0 never, 1 wherever the shapes allow
@@ -1655,6 +1757,8 @@ void free_workspace(ttsx_t2_decoder* d) {
   d->len_ws = nullptr;
   if (d->win_idx) (void)hipFree(d->win_idx);
   d->win_idx = nullptr;
+  if (d->x1_flags) (void)hipFree(d->x1_flags);
+  d->x1_flags = nullptr;
   d->cap_B = 0;
 }
 
@@ -1687,6 +1791,7 @@ int ensure_workspace(ttsx_t2_decoder* d, int B, int T) {
     rc |= dev_alloc(&d->len_ws, cb);
     rc |= dev_alloc(&d->u_fa, cb);
     rc |= dev_alloc(&d->win_idx, cb);
+    rc |= dev_alloc(&d->x1_flags, (size_t)ceil_div((int)cb, 16) * (PRENET_DIM / 16));
     rc |= dev_alloc(&d->mu, cb * GRAVES_MAX_K);
     rc |= dev_alloc(&d->n1, QUERY_DIM * cb);
     rc |= dev_alloc(&d->gbk, (size_t)round_up(3 * GRAVES_MAX_K, 16) * cb);
@@ -1959,11 +2064,18 @@ int enqueue_step(ttsx_t2_decoder* d, int i, bool first, bool more, hipStream_t s
   g.Wp = d->w_pre2, g.bias = d->b_pre2, g.nseg = 1, g.KG = PRENET_DIM / 16, g.kg0 = 0, g.kg_stride = g.KG;
   g.seg[0] = Seg{{d->x1, nullptr}, 0, PRENET_DIM / 16};
   g.out[0] = d->x2, g.relu = 1;
+  const GemmP g_pre2 = g;
+  // MFMA engine: inside a chunk, prenet layer 2 of a step (and both K halves of its early attention-LSTM columns)
+  // ran in the projection launch of the step before it
+  // (measured per step, own launch / fused, T=128 unless noted: B=32 38.7 / 39.9 us, B=48 48.1 / 46.9, B=64 48.2 /
+  // 46.6, B=64 T=256 52.2 / 50.9, B=64 T=64 (no split) 49.1 / 51.4, B=128 (no split) 73.3 / 76.4: it pays where the
+  // early/late split is on at padded batch 64, and costs where the fused launch has no piece work to hide behind)
+  const bool fuse_p2 = mfma && (d->plan_fuse_p2 == 1 || (d->plan_fuse_p2 == -1 && split && Bpad == 64));
   // (pieces of the attention partial: thirds of the rows behind decoder LSTM / projection / prenet at batch 1-2;
   // on the MFMA engine the two halves of K behind projection / prenet)
   pc = mfma ? k_piece(pa, 1) : pa.piece(2);
   pc.on = split && !first;
-  if ((rc = launch_gemm<MODE_LINEAR, 2, PK1>(d, g, PRENET_DIM / 16, false, &pc, st))) return rc;
+  if (!(fuse_p2 && !first) && (rc = launch_gemm<MODE_LINEAR, 2, PK1>(d, g, PRENET_DIM / 16, false, &pc, st))) return rc;
   // attention LSTM: [x2; ctx; h_a] (split: late columns [x2] + the partial sums) + cell update
   g.Wp = d->w_lstm1, g.bias = d->b_lstm1, g.kg0 = 0, g.kg_stride = KG1;
   g.seg[0] = Seg{{d->x2, nullptr}, 0, PRENET_DIM / 16};
@@ -2082,6 +2194,30 @@ int enqueue_step(ttsx_t2_decoder* d, int i, bool first, bool more, hipStream_t s
   g.out[0] = d->o, g.out[1] = nullptr, g.c = nullptr, g.x1 = d->x1, g.o_quads = MEL_DIM * d->proj_r / 4;
   pc = mfma ? k_piece(pa_next, 0) : pa_next.piece(1);
   pc.on = split && more;
+  if (fuse_p2 && more) {
+    // + prenet layer 2 of the next step behind flags of this launch's own row blocks, + both K halves of the piece
+    pc.nk = 2;
+    GemmP g2 = g_pre2;
+    g2.x1_flags = d->x1_flags;  // (step_in_chunk stays this step's: the tag the row blocks raise)
+    g.x1_flags = d->x1_flags;
+    const int nt = Bpad / 16, nrb = ceil_div(proj_rows(d->proj_r), 16);
+    g.rb0 = 0, g.nrb = nrb;
+    const int na = nrb * nt, nc = (PRENET_DIM / 16) * nt;
+    typedef GemmOp<1, 1, 12, MODE_PROJ> ProjOp;
+    if (!pc.on) {
+      triple_kernel<ProjOp, Prenet2AfterProjOp, NoOp><<<na + nc, GEMM_THREADS, 0, st>>>(g, g2, 0, na, nc);
+    } else if (nt % 2 == 0 && pc.g.nrb % 2 == 0) {
+      const int nb = pc.g.nrb / 2 * (nt / 2) * pc.nk;
+      triple_kernel<ProjOp, Prenet2AfterProjOp, GemmOp<2, 2, PK1 / 2, MODE_PARTIAL>>
+          <<<na + nc + nb, GEMM_THREADS, 0, st>>>(g, g2, pc.g, na, nc);
+    } else {
+      const int nb = pc.g.nrb * nt * pc.nk;
+      triple_kernel<ProjOp, Prenet2AfterProjOp, GemmOp<1, 1, PK1 / 2, MODE_PARTIAL>>
+          <<<na + nc + nb, GEMM_THREADS, 0, st>>>(g, g2, pc.g, na, nc);
+    }
+    TTSX_LAUNCH_CHECK();
+    return TTSX_OK;
+  }
   return launch_gemm<MODE_PROJ, 12, PK1>(d, g, ceil_div(proj_rows(d->proj_r), 16), false, &pc, st);
 }
 
@@ -2097,7 +2233,7 @@ int push_ctx(ttsx_t2_decoder* d, hipStream_t st) {
 int launch_chunk(ttsx_t2_decoder* d, int n, int chunk, hipStream_t st) {
   if (n == chunk) {
     ttsx_t2_decoder::ChunkGraph& g = d->graphs[chunk == CHUNK ? 0 : 1];   // (the cache key includes the chunk size)
-    const int split = (int)d->split + 2 * (int)d->share_q;
+    const int split = (int)d->split + 2 * (int)d->share_q + 4 * (d->plan_fuse_p2 + 1);
     const bool cached = g.exec && g.B == d->B && g.T == d->T && g.r == d->rc_host->r && g.gen == d->ws_gen &&
                         g.chunk == n && g.split == split && g.fused == (int)d->fused;
     if (!cached) {
@@ -2164,7 +2300,7 @@ extern "C" int ttsx_t2_decoder_create(const ttsx_t2_decoder_weights* w, int r_in
   ScopeExit on_fail([&] { (void)ttsx_t2_decoder_destroy(d); });
   ScopeExit free_tmp([&] { (void)hipFree(w_ih2), (void)hipFree(a2f), (void)hipFree(b2f); });
   d->r_init = r_init, d->norm = attn_norm, d->odim = MEL_DIM * r_init;
-  d->plan_fused = d->plan_split = d->plan_share_q = d->plan_team = -1;
+  d->plan_fused = d->plan_split = d->plan_share_q = d->plan_team = d->plan_fuse_p2 = -1;
   int rc = 0;
   rc |= pack_layer(&d->w_lstm1, &d->b_lstm1, w->attn_rnn_w_ih, PRENET_DIM + ENC_DIM, w->attn_rnn_w_hh, QUERY_DIM,
                    w->attn_rnn_b_ih, w->attn_rnn_b_hh, 4 * QUERY_DIM, QUERY_DIM, st);
@@ -2392,6 +2528,7 @@ extern "C" int ttsx_t2_decoder_begin(ttsx_t2_decoder* d, const float* enc, const
   TTSX_HIP(hipMemsetAsync(d->o, 0, sizeof(float) * (size_t)round_up(proj_rows(d->r_init), 16) * cb, st));
   TTSX_HIP(hipMemsetAsync(d->n1, 0, sizeof(float) * QUERY_DIM * cb, st));
   TTSX_HIP(hipMemsetAsync(d->gbk, 0, sizeof(float) * (size_t)round_up(3 * GRAVES_MAX_K, 16) * cb, st));
+  TTSX_HIP(hipMemsetAsync(d->x1_flags, 0, sizeof(unsigned) * ceil_div((int)cb, 16) * (PRENET_DIM / 16), st));
   TTSX_HIP(hipMemsetAsync(d->a_prev, 0, sizeof(float) * (size_t)B * T, st));
   TTSX_HIP(hipMemsetAsync(d->a_cum, 0, sizeof(float) * (size_t)B * T, st));
   if (d->mem0_set) {
@@ -2587,8 +2724,14 @@ extern "C" int ttsx_t2_decoder_run(ttsx_t2_decoder* d, const float* enc, const i
   finalize_steps_kernel<<<ceil_div(B, 256), 256, 0, st>>>(n_steps, B, launched);
   TTSX_LAUNCH_CHECK();
   std::vector<int32_t> host(B);
+  int sync_failed = 0;
   TTSX_HIP(hipMemcpyAsync(host.data(), n_steps, sizeof(int32_t) * B, hipMemcpyDeviceToHost, st));
+  TTSX_HIP(hipMemcpyAsync(&sync_failed, &d->rc->sync_failed, sizeof(int), hipMemcpyDeviceToHost, st));
   TTSX_HIP(hipStreamSynchronize(st));
+  if (sync_failed) {
+    ttsx_set_error("ttsx_t2_decoder_run: a prenet workgroup waited too long for the projection rows of its own launch");
+    return TTSX_ERR_STATE;
+  }
   int run = 0;
   for (int b = 0; b < B; ++b) run = std::max(run, (int)host[b]);
   if (fixed_steps) run = launched;
@@ -2604,6 +2747,14 @@ extern "C" int ttsx_t2_decoder_set_plan(ttsx_t2_decoder* d, int fused_attention,
   for (int v : {fused_attention, split_lstm, share_query})
     TTSX_ARG(v >= -1 && v <= 1, "ttsx_t2_decoder_set_plan: %d is not -1 (by shape), 0 (off) or 1 (on)", v);
   d->plan_fused = fused_attention, d->plan_split = split_lstm, d->plan_share_q = share_query;
+  return TTSX_OK;
+}
+
+extern "C" int ttsx_t2_decoder_set_fusion(ttsx_t2_decoder* d, int prenet_in_projection) {
+  TTSX_ARG(d, "ttsx_t2_decoder_set_fusion: null handle");
+  TTSX_ARG(prenet_in_projection >= -1 && prenet_in_projection <= 1,
+           "ttsx_t2_decoder_set_fusion: %d is not -1 (default), 0 (off) or 1 (on)", prenet_in_projection);
+  d->plan_fuse_p2 = prenet_in_projection;
   return TTSX_OK;
 }
 

@@ -328,6 +328,11 @@ class Tacotron2:
         _lib.check(_lib.load().ttsx_t2_decoder_set_plan(self._dec_handle, int(fused_attention), int(split_lstm),
                                                         int(share_query)), "ttsx_t2_decoder_set_plan")
 
+    def set_fusion(self, prenet_in_projection=-1):
+        """Batched decode: prenet layer 2 inside the previous step's projection launch (ttsx_t2_decoder_set_fusion)."""
+        _lib.check(_lib.load().ttsx_t2_decoder_set_fusion(self._dec_handle, int(prenet_in_projection)),
+                   "ttsx_t2_decoder_set_fusion")
+
     def set_team(self, team=-1):
         """Whether batch-1 runs may use the persistent team kernel (ttsx_t2_decoder_set_team): -1 by shape, 0 never,
         1 wherever the shapes allow."""
