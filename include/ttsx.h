@@ -159,9 +159,9 @@ int ttsx_t2_decoder_set_plan(ttsx_t2_decoder* dec, int fused_attention, int spli
 int ttsx_t2_decoder_set_fusion(ttsx_t2_decoder* dec, int prenet_in_projection);
 
 /* Whether a run of one or two utterances may use the persistent team kernel (no reference counterpart): texts of up to
- * 256 symbols, reduction factor 1-2, plain location-sensitive attention, no state carried over by
+ * 1024 symbols, reduction factor 1-2, plain location-sensitive attention, no state carried over by
  * ttsx_t2_decoder_set_initial.  One launch decodes a whole utterance (two utterances: two launches) with all decoder weights held in the
- * registers and LDS of 216 workgroups, which must be resident together (one CU each): meant for a GPU that serves one
+ * registers and LDS of 216 workgroups (240 beyond 256 symbols), which must be resident together (one CU each): meant for a GPU that serves one
  * request stream.  -1 by shape (default; a run whose team cannot become resident falls back to the launch chain and
  * the handle stays with it), 0 never, 1 wherever the shapes allow (such a run fails with TTSX_ERR_STATE instead). */
 int ttsx_t2_decoder_set_team(ttsx_t2_decoder* dec, int team);

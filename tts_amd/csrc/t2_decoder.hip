@@ -2651,8 +2651,8 @@ extern "C" int ttsx_t2_decoder_run(ttsx_t2_decoder* d, const float* enc, const i
   rc = ttsx_t2_decoder_begin(d, enc, enc_len, B, T, stream);
   if (rc) return rc;
   TTSX_HIP(hipMemsetAsync(n_steps, 0, sizeof(int32_t) * B, st));
-  // One or two utterances of up to 256 symbols with the plain location-sensitive attention: the run of an
-  // utterance is one persistent launch of a 216-workgroup team that keeps every weight in registers and LDS
+  // One or two utterances of up to 1024 symbols with the plain location-sensitive attention: the run of an
+  // utterance is one persistent launch of a 216-workgroup team (240 beyond 256 symbols) that keeps every weight in registers and LDS
   // (t2_team.hip; 11.7 us per step against 31.7 for the chain at batch 1, and two such runs one after the other
   // still beat the chain's 35 us per step at batch 2).
   if (B <= 2 && t2_team_supports(d->team, 1, T, r) && !carried && !d->variant && d->graves_K == 0 &&

@@ -30,7 +30,7 @@ void t2_team_destroy(t2_team* t);
 // Projection rows for reduction factor r, row-major [80 r + 16 + 256][1536] over [h_d; ctx] with their biases:
 // the 80 r mel rows, the composed stop-logit row (first of 16), the 256 composed prenet-layer-1 rows.
 int t2_team_set_proj(t2_team* t, const float* rows_w, const float* rows_b, int r, hipStream_t st);
-// Shapes the team kernel covers: one utterance, encoder length up to 256, reduction factor 1-2.
+// Shapes the team kernel covers: one utterance, encoder length up to 1024, reduction factor 1-2.
 bool t2_team_supports(const t2_team* t, int B, int T, int r);
 // One greedy decode (the contract of ttsx_t2_decoder_run, include/ttsx.h, for B = 1).  enc [T,512], P [T,128]
 // processed inputs, len [1] on the device.  TTSX_ERR_STATE: the team's workgroups did not become resident together.

@@ -16,6 +16,10 @@
 //      processed inputs of the utterance in registers, location layers in LDS; they publish partial energies;
 //   *   4 context workgroups, one per 128 encoder columns, with the utterance's encoder outputs in registers: they
 //      add the partial energies, normalise and publish their slice of the context.
+// Texts beyond 256 symbols (up to 1024) run with 16 + 16 attention workgroups (240 in all): the encoder axis is cut
+// into four chunks of 256 positions, every energy / context workgroup owns one chunk of one slice, all of them
+// normalise over all positions from the same partial energies, and the context travels as four partial vectors
+// that its consumers add in a fixed order.
 // Only activations cross the chip, as in the Tacotron (v1) team kernel (t1_team.hip): 64-bit words (step tag,
 // fp32 value) in small exchange buffers, written with one contiguous store per workgroup and vector, polled once
 // per workgroup (thread i polls word i) and handed on through LDS.  Six exchanges lie on a step's serial chain:
@@ -36,9 +40,8 @@ typedef unsigned long long u64;
 constexpr int NT = 512;
 constexpr int QD = 1024, DD = 1024, ED = 512, PD = 256, AD = 128, MEL = 80;
 constexpr int LOCF = 32, LOCK = 31, LPAD = 15, TMAX = 256;  // (attention roles are built for 128 and for 256 positions)
-constexpr int N_ATT = 64, N_DEC = 128, N_PROJ = 16, N_EN = 4, N_CTX = 4;
-constexpr int G_DEC0 = N_ATT, G_PROJ0 = G_DEC0 + N_DEC, G_EN0 = G_PROJ0 + N_PROJ, G_CTX0 = G_EN0 + N_EN,
-              G_TOTAL = G_CTX0 + N_CTX;
+constexpr int N_ATT = 64, N_DEC = 128, N_PROJ = 16, N_EN = 4;  // (and as many context workgroups as energy workgroups)
+constexpr int G_DEC0 = N_ATT, G_PROJ0 = G_DEC0 + N_DEC, G_EN0 = G_PROJ0 + N_PROJ;
 constexpr unsigned DONE_BIT = 0x80000000u;
 constexpr long SPIN_LIMIT = 4000000;
 constexpr int PROJ_K = DD + ED;
@@ -51,8 +54,10 @@ constexpr int NS_EN = 64;
 constexpr int LDS_W = 32768;  // floats of weights in the LDS of an LSTM workgroup
 
 // exchange buffers (u64 words); one block per step parity.  Vectors that one workgroup polls together are neighbours.
-constexpr int X_HA = 0, X_CTX = X_HA + QD, X_HD = X_CTX + ED, X_X1 = X_HD + DD, X_X1_N = 272 /* 256 + control */,
-              X_X2 = X_X1 + X_X1_N, X_EP = X_X2 + PD, X_PAR = X_EP + N_EN * TMAX;
+// The context travels as NC partial vectors (one per chunk of 256 encoder positions; NC = 1 up to 256 positions).
+constexpr int NC_MAX = 4;
+constexpr int X_HA = 0, X_CTX = X_HA + QD, X_HD = X_CTX + NC_MAX * ED, X_X1 = X_HD + DD, X_X1_N = 272 /* 256 + control */,
+              X_X2 = X_X1 + X_X1_N, X_EP = X_X2 + PD, X_PAR = X_EP + N_EN * NC_MAX * 256;
 
 struct T2P {
   const float *img_att, *lds_att, *img_dec, *lds_dec, *img_proj, *img_en;
@@ -109,6 +114,42 @@ __device__ __forceinline__ int poll_span(const u64* X, int n, unsigned tag, floa
 template <int N>
 __device__ __forceinline__ int fetch_span(const u64* X, int n, unsigned tag, float* dst, int* abort_word, int* s_flag) {
   const int st = poll_span<N>(X, n, tag, dst, abort_word);
+  if (st && (threadIdx.x & 63) == 0) atomicOr(s_flag, st);
+  __syncthreads();
+  return *s_flag;
+}
+
+// The same over two spans that are not neighbours in memory: words [0, na) of XA, then words [0, nb) of XB.
+template <int N>
+__device__ __forceinline__ int fetch_span2(const u64* XA, int na, const u64* XB, int nb, unsigned tag, float* dst,
+                                           int* abort_word, int* s_flag) {
+  const int tid = threadIdx.x, n = na + nb;
+  int st = -1;
+  for (long spin = 0; st < 0; ++spin) {
+    u64 v[N];
+    bool ok = true, dn = false;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      const int idx = min(tid + NT * j, n - 1);
+      v[j] = __hip_atomic_load(idx < na ? XA + idx : XB + (idx - na), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned tf = (unsigned)(v[j] >> 32);
+      ok = ok && (tid + NT * j >= n || (tf & ~DONE_BIT) == tag);
+      dn = dn || (tid + NT * j < n && (tf & DONE_BIT) != 0);
+    }
+    if (__all(ok)) {
+#pragma unroll
+      for (int j = 0; j < N; ++j)
+        if (tid + NT * j < n) dst[tid + NT * j] = __uint_as_float((unsigned)v[j]);
+      st = __any(dn) ? 2 : 0;
+    } else if ((spin & 127) == 127 && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+      st = 1;
+    } else if (spin > SPIN_LIMIT) {
+      __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      st = 1;
+    } else {
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
   if (st && (threadIdx.x & 63) == 0) atomicOr(s_flag, st);
   __syncthreads();
   return *s_flag;
@@ -184,13 +225,14 @@ __device__ __forceinline__ float normalise(float e, bool valid, int norm, float*
 }
 
 // ------------------------------------------------------------------ attention LSTM: 16 hidden units
+template <int NC>
 __device__ void att_role(const T2P& p, int a, float* sm) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   float* s_wc = sm;                 // [wave][8 rows][8][64] columns over the context
   float* s_x2 = s_wc + LDS_W;       // [256]
-  float* s_hc = s_x2 + PD;          // [1024] h_a(t-1), [512] ctx(t-1)
-  float* s_pub = s_hc + QD + ED;    // [16]
+  float* s_hc = s_x2 + PD;          // [1024] h_a(t-1), [NC][512] partial contexts of step t-1
+  float* s_pub = s_hc + QD + NC * ED;  // [16]
   int* s_flag = reinterpret_cast<int*>(s_pub + 16);
   float w[NS_ATT];
   {
@@ -212,12 +254,16 @@ __device__ void att_role(const T2P& p, int a, float* sm) {
 #pragma unroll
     for (int ri = 0; ri < 8; ++ri) acc[ri] = 0.f;
     if (t > 0) {
-      if (fetch_span<3>(Xp + X_HA, QD + ED, tag - 1, s_hc, p.abort_word, s_flag) & 1) return;
+      if (fetch_span<(QD + NC * ED) / NT>(Xp + X_HA, QD + NC * ED, tag - 1, s_hc, p.abort_word, s_flag) & 1) return;
       float hv[16], cv[8];
 #pragma unroll
       for (int j = 0; j < 16; ++j) hv[j] = s_hc[lane + 64 * j];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) cv[j] = s_hc[QD + lane + 64 * j];
+      for (int j = 0; j < 8; ++j) {
+        cv[j] = s_hc[QD + lane + 64 * j];
+#pragma unroll
+        for (int c = 1; c < NC; ++c) cv[j] += s_hc[QD + c * ED + lane + 64 * j];
+      }
 #pragma unroll
       for (int ri = 0; ri < 8; ++ri) {
         float s = 0.f;
@@ -261,14 +307,15 @@ __device__ void att_role(const T2P& p, int a, float* sm) {
 }
 
 // ------------------------------------------------------------------ decoder LSTM: 8 hidden units
+template <int NC>
 __device__ void dec_role(const T2P& p, int d, float* sm) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   float* s_wh = sm;                 // [wave][4 rows][16][64] columns over h_d(t-1)
   float* s_hd = s_wh + LDS_W;       // [1024]
   float* s_ha = s_hd + DD;          // [1024]
-  float* s_ctx = s_ha + QD;         // [512]
-  float* s_pub = s_ctx + ED;        // [8]
+  float* s_ctx = s_ha + QD;         // [NC][512]
+  float* s_pub = s_ctx + NC * ED;   // [8]
   int* s_flag = reinterpret_cast<int*>(s_pub + 8);
   float w[NS_DEC];
   {
@@ -317,11 +364,15 @@ __device__ void dec_role(const T2P& p, int d, float* sm) {
       }
     }
     // ---- the columns over the context, the cell update
-    if (fetch_span<1>(Xc + X_CTX, ED, tag, s_ctx, p.abort_word, s_flag) & 1) return;
+    if (fetch_span<NC>(Xc + X_CTX, NC * ED, tag, s_ctx, p.abort_word, s_flag) & 1) return;
     {
       float cv[8], g4[4];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) cv[j] = s_ctx[lane + 64 * j];
+      for (int j = 0; j < 8; ++j) {
+        cv[j] = s_ctx[lane + 64 * j];
+#pragma unroll
+        for (int c = 1; c < NC; ++c) cv[j] += s_ctx[c * ED + lane + 64 * j];
+      }
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         float s = acc[g];
@@ -347,11 +398,12 @@ __device__ void dec_role(const T2P& p, int d, float* sm) {
 // Wave w of workgroup q owns: the composed prenet-1 rows 16 q + 2 w, + 1 (slots 0, 1), the mel rows
 // q + 16 (w + 8 i), i = 0, 1 (slots 2, 3; below 80 r), and - wave 7 of workgroup 15 - the composed stop row (slot 4);
 // prenet-2 rows 16 q + 2 w, + 1.
+template <int NC>
 __device__ void proj_role(const T2P& p, int q, float* sm) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  float* s_in = sm;                 // [512] ctx, [1024] h_d
-  float* s_x1 = s_in + ED + DD;     // [257]
+  float* s_in = sm;                 // [NC][512] partial contexts, [1024] h_d
+  float* s_x1 = s_in + NC * ED + DD;  // [257]
   float* s_pub = s_x1 + X_X1_N;     // [16] x1 slice, [16] x2 slice
   int* s_flag = reinterpret_cast<int*>(s_pub + 32);
   float w[NS_PROJ];
@@ -365,16 +417,25 @@ __device__ void proj_role(const T2P& p, int q, float* sm) {
   const bool owner = q == N_PROJ - 1 && wave == 7;  // of the stop row
   const int n_mel = MEL * p.r;
   int n_stop = 0;  // 1-based step of the first stop token above the threshold (owner wave)
+  float xctx[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // the context of the last step projected
   for (int t = 0;; ++t) {
     const unsigned tag = (unsigned)t + 1u;
     u64* Xc = p.xch + (size_t)(t & 1) * X_PAR;
     const u64* Xp = p.xch + (size_t)((t & 1) ^ 1) * X_PAR;
     if (t > 0) {
       // ---- the projection of step t - 1: frames, stop token, prenet layer 1 of the fed-back frame
-      if (fetch_span<3>(Xp + X_CTX, ED + DD, tag - 1, s_in, p.abort_word, s_flag) & 1) return;
+      if (fetch_span2<(NC * ED + DD) / NT>(Xp + X_CTX, NC * ED, Xp + X_HD, DD, tag - 1, s_in, p.abort_word, s_flag) & 1)
+        return;
       float xin[24];
 #pragma unroll
-      for (int j = 0; j < 24; ++j) xin[j] = j < 16 ? s_in[ED + lane + 64 * j] : s_in[lane + 64 * (j - 16)];
+      for (int j = 0; j < 16; ++j) xin[j] = s_in[NC * ED + lane + 64 * j];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float cvj = s_in[lane + 64 * j];
+#pragma unroll
+        for (int c = 1; c < NC; ++c) cvj += s_in[c * ED + lane + 64 * j];
+        xin[16 + j] = cvj, xctx[j] = cvj;
+      }
       float val[5];
 #pragma unroll
       for (int rs = 0; rs < 5; ++rs) {
@@ -429,6 +490,10 @@ __device__ void proj_role(const T2P& p, int q, float* sm) {
   }
   // what the next step would have been fed, the step count
   if (p.st.x1 && wave == 0 && lane < 16) p.st.x1[16 * q + lane] = s_pub[lane];
+  if (p.st.ctx && q == 0 && wave == 0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) p.st.ctx[lane + 64 * j] = xctx[j];
+  }
   if (owner && lane == 0) p.n_steps[0] = n_stop;
 }
 
@@ -593,7 +658,6 @@ __device__ void ctx_role(const T2P& p, int c, float* sm) {
   const float vb = p.v_b[0];
   if (tid == 0) *s_flag = 0;
   __syncthreads();
-  float last = 0.f;
   for (int t = 0; t < p.S; ++t) {
     const unsigned tag = (unsigned)t + 1u;
     u64* Xc = p.xch + (size_t)(t & 1) * X_PAR;
@@ -619,27 +683,252 @@ __device__ void ctx_role(const T2P& p, int c, float* sm) {
       s_cp[tq * 128 + col] = a0 + a1;
     }
     __syncthreads();
-    if (tid < 128) {
-      last = (s_cp[tid] + s_cp[128 + tid]) + (s_cp[256 + tid] + s_cp[384 + tid]);
-      publish(Xc + X_CTX, 128 * c + tid, last, tag);
-    }
+    if (tid < 128) publish(Xc + X_CTX, 128 * c + tid, (s_cp[tid] + s_cp[128 + tid]) + (s_cp[256 + tid] + s_cp[384 + tid]), tag);
   }
-  if (p.st.ctx && tid < 128) p.st.ctx[128 * c + tid] = last;
 }
 
-template <int TM>
+// ------------------------------------------------------------------ long texts: NC chunks of 256 positions
+// Alignment weights of ALL NC * 256 positions from the partial energies in LDS ([4][NC * 256]): every energy and
+// context workgroup of a long-text team runs exactly this, then uses its own chunk.  A thread holds positions
+// tid + 512 j.  Called by all threads; the caller synchronises before s_al is read.
+template <int NC>
+__device__ __forceinline__ void normalise_all(const float* s_e4, float vb, int len, int norm, float* s_al, float* s_red) {
+  constexpr int TS = NC * 256, NPT = TS / NT;
+  static_assert(TS % NT == 0, "two chunks per 512 threads");
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const bool softmax = norm == TTSX_NORM_SOFTMAX;
+  float en[NPT];
+#pragma unroll
+  for (int j = 0; j < NPT; ++j) {
+    const int i = tid + NT * j;
+    en[j] = ((s_e4[i] + s_e4[TS + i]) + (s_e4[2 * TS + i] + s_e4[3 * TS + i])) + vb;
+  }
+  float m = 0.f;
+  if (softmax) {
+    float x = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) x = fmaxf(x, tid + NT * j < len ? en[j] : -INFINITY);
+    x = wmax(x);
+    if (lane == 0) s_red[wave] = x;
+    __syncthreads();
+    m = s_red[0];
+#pragma unroll
+    for (int i = 1; i < NT / 64; ++i) m = fmaxf(m, s_red[i]);
+  }
+  float v[NPT], part = 0.f;
+#pragma unroll
+  for (int j = 0; j < NPT; ++j) {
+    v[j] = tid + NT * j < len ? (softmax ? expf(en[j] - m) : sigmoidf_(en[j])) : 0.f;
+    part += v[j];
+  }
+  part = wsum(part);
+  if (lane == 0) s_red[8 + wave] = part;
+  __syncthreads();
+  float sum = s_red[8];
+#pragma unroll
+  for (int i = 1; i < NT / 64; ++i) sum += s_red[8 + i];
+#pragma unroll
+  for (int j = 0; j < NPT; ++j) s_al[tid + NT * j] = v[j] / sum;
+}
+
+// Energies of one chunk of 256 positions over 32 attention dimensions: workgroup ge = 4 * chunk + slice.
+template <int NC>
+__device__ void energy_long_role(const T2P& p, int ge, float* sm) {
+  constexpr int TS = NC * 256, NPT = TS / NT, ND = 16, CP = 16;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int e = ge & 3, base = 256 * (ge >> 2);
+  const int T = p.T, len = min(max(p.len[0], 0), T);
+  float* s_wl = sm;                              // [62][32] location conv, filter fastest
+  float* s_wld = s_wl + 2 * LOCK * LOCF;         // [32 own dims][32]
+  float* s_v = s_wld + 32 * LOCF;                // [32]
+  float* s_prev = s_v + 32;                      // [TS + 32] previous alignment of ALL positions, 15 zeros in front
+  float* s_cum = s_prev + TS + 32;               // [TS + 32] cumulative alignment
+  float* s_cf = s_cum + TS + 32;                 // [256][33] conv features of the own chunk
+  float* s_ha = s_cf + 256 * (LOCF + 1);         // [1024]
+  float* s_q = s_ha + QD;                        // [32]
+  float* s_ep = s_q + 32;                        // [2][256]
+  float* s_e4 = s_ep + 2 * 256;                  // [4][TS] partial energies of all positions
+  float* s_al = s_e4 + 4 * TS;                   // [TS]
+  float* s_red = s_al + TS;                      // [16]
+  int* s_flag = reinterpret_cast<int*>(s_red + 16);
+  float wq[NS_EN];
+  {
+    const float* img = p.img_en + ((size_t)e * NS_EN) * NT + tid;
+#pragma unroll
+    for (int s = 0; s < NS_EN; ++s) wq[s] = img[(size_t)s * NT];
+  }
+  for (int i = tid; i < 2 * LOCK * LOCF; i += NT) s_wl[i] = p.conv_t[i];
+  for (int i = tid; i < 32 * LOCF; i += NT) s_wld[i] = p.loc_dense[(size_t)32 * e * LOCF + i];
+  if (tid < 32) s_v[tid] = p.v_w[32 * e + tid];
+  for (int i = tid; i < 2 * (TS + 32); i += NT) s_prev[i] = 0.f;  // (s_prev and s_cum are neighbours)
+  if (tid == 0) *s_flag = 0;
+  const int pos = tid & 255, dq = tid >> 8, gpos = base + pos;
+  float pp[ND], pl[ND];
+#pragma unroll
+  for (int i = 0; i < ND; ++i) pp[i] = gpos < len ? p.P[(size_t)gpos * AD + 32 * e + ND * dq + i] : 0.f;
+  const float vb = p.v_b[0];
+  __syncthreads();
+  auto location_terms = [&]() {
+    {
+      const int f = tid & 31, tp = tid >> 5;
+      float acc[CP];
+#pragma unroll
+      for (int i = 0; i < CP; ++i) acc[i] = 0.f;
+#pragma unroll
+      for (int ch = 0; ch < 2; ++ch) {
+        const float* a = (ch ? s_cum : s_prev) + base + CP * tp;
+        float win[LOCK + CP - 1];
+#pragma unroll
+        for (int j = 0; j < LOCK + CP - 1; ++j) win[j] = a[j];
+#pragma unroll
+        for (int j = 0; j < LOCK; ++j) {
+          const float wv = s_wl[(ch * LOCK + j) * LOCF + f];
+#pragma unroll
+          for (int i = 0; i < CP; ++i) acc[i] += wv * win[j + i];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < CP; ++i) s_cf[(CP * tp + i) * (LOCF + 1) + f] = acc[i];
+    }
+    __syncthreads();
+    float cf[LOCF];
+#pragma unroll
+    for (int f = 0; f < LOCF; ++f) cf[f] = s_cf[pos * (LOCF + 1) + f];
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+      const float4* wl = reinterpret_cast<const float4*>(s_wld + (ND * dq + i) * LOCF);
+      float loc = 0.f;
+#pragma unroll
+      for (int f4 = 0; f4 < LOCF / 4; ++f4) {
+        const float4 w4 = wl[f4];
+        loc += w4.x * cf[4 * f4] + w4.y * cf[4 * f4 + 1] + w4.z * cf[4 * f4 + 2] + w4.w * cf[4 * f4 + 3];
+      }
+      pl[i] = pp[i] + loc;
+      asm volatile("" : "+v"(pl[i])::"memory");
+    }
+  };
+  location_terms();
+  for (int t = 0; t < p.S; ++t) {
+    const unsigned tag = (unsigned)t + 1u;
+    u64* Xc = p.xch + (size_t)(t & 1) * X_PAR;
+    const int st = fetch_span<2>(Xc + X_HA, QD, tag, s_ha, p.abort_word, s_flag);
+    if (st & 1) return;
+    if (st & 2) {
+      if (tid < 256) publish(Xc + X_EP, e * TS + base + tid, 0.f, tag | DONE_BIT);
+      return;
+    }
+    {
+      float hv[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) hv[j] = s_ha[lane + 64 * j];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) s += wq[i * 16 + j] * hv[j];
+        const float qv = wsum(s);
+        if (lane == 0) s_q[4 * wave + i] = qv;
+      }
+    }
+    __syncthreads();
+    {
+      const float4* q4 = reinterpret_cast<const float4*>(s_q + ND * dq);
+      const float4* v4 = reinterpret_cast<const float4*>(s_v + ND * dq);
+      float e0 = 0.f, e1 = 0.f;
+#pragma unroll
+      for (int i = 0; i < ND / 4; ++i) {
+        const float4 qv = q4[i], v = v4[i];
+        e0 += v.x * fast_tanhf(qv.x + pl[4 * i]) + v.z * fast_tanhf(qv.z + pl[4 * i + 2]);
+        e1 += v.y * fast_tanhf(qv.y + pl[4 * i + 1]) + v.w * fast_tanhf(qv.w + pl[4 * i + 3]);
+      }
+      s_ep[dq * 256 + pos] = e0 + e1;
+    }
+    __syncthreads();
+    if (tid < 256) publish(Xc + X_EP, e * TS + base + tid, s_ep[tid] + s_ep[256 + tid], tag);
+    // ---- off the serial chain: this step's alignment over all positions
+    if (fetch_span<4 * TS / NT>(Xc + X_EP, 4 * TS, tag, s_e4, p.abort_word, s_flag) & 1) return;
+    normalise_all<NC>(s_e4, vb, len, p.norm, s_al, s_red);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) {
+      const int i = tid + NT * j;
+      const float a = s_al[i];
+      s_prev[LPAD + i] = a;
+      s_cum[LPAD + i] += a;
+      if (ge == 0 && i < T) p.align[(size_t)t * T + i] = a;
+    }
+    __syncthreads();
+    location_terms();
+  }
+}
+
+// Partial context of one chunk of 256 positions over 128 encoder columns: workgroup gc = 4 * chunk + column slice.
+template <int NC>
+__device__ void ctx_long_role(const T2P& p, int gc, float* sm) {
+  constexpr int TS = NC * 256, NP = 64;
+  const int tid = threadIdx.x;
+  const int cs = gc & 3, chunk = gc >> 2, base = 256 * chunk;
+  const int T = p.T, len = min(max(p.len[0], 0), T);
+  float* s_e4 = sm;                    // [4][TS]
+  float* s_al = s_e4 + 4 * TS;         // [TS]
+  float* s_cp = s_al + TS;             // [4][128]
+  float* s_red = s_cp + 4 * 128;       // [16]
+  int* s_flag = reinterpret_cast<int*>(s_red + 16);
+  const int col = tid & 127, tq = tid >> 7;
+  float er[NP];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int ps = base + NP * tq + i;
+    er[i] = ps < len ? p.enc[(size_t)ps * ED + 128 * cs + col] : 0.f;
+  }
+  const float vb = p.v_b[0];
+  if (tid == 0) *s_flag = 0;
+  __syncthreads();
+  for (int t = 0; t < p.S; ++t) {
+    const unsigned tag = (unsigned)t + 1u;
+    u64* Xc = p.xch + (size_t)(t & 1) * X_PAR;
+    const int st = fetch_span<4 * TS / NT>(Xc + X_EP, 4 * TS, tag, s_e4, p.abort_word, s_flag);
+    if (st & 1) return;
+    if (st & 2) break;
+    normalise_all<NC>(s_e4, vb, len, p.norm, s_al, s_red);
+    __syncthreads();
+    {
+      const float4* a4 = reinterpret_cast<const float4*>(s_al + base + NP * tq);
+      float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+      for (int i = 0; i < NP / 4; ++i) {
+        const float4 av = a4[i];
+        a0 += av.x * er[4 * i] + av.z * er[4 * i + 2];
+        a1 += av.y * er[4 * i + 1] + av.w * er[4 * i + 3];
+      }
+      s_cp[tq * 128 + col] = a0 + a1;
+    }
+    __syncthreads();
+    if (tid < 128)
+      publish(Xc + X_CTX, chunk * ED + 128 * cs + tid, (s_cp[tid] + s_cp[128 + tid]) + (s_cp[256 + tid] + s_cp[384 + tid]), tag);
+  }
+}
+
+template <int TM, int NC>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void t2_team_kernel(T2P p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int g = blockIdx.x;
-  if (g < G_DEC0) att_role(p, g, sm);
-  else if (g < G_PROJ0) dec_role(p, g - G_DEC0, sm);
-  else if (g < G_EN0) proj_role(p, g - G_PROJ0, sm);
-  else if (g < G_CTX0) energy_role<TM>(p, g - G_EN0, sm);
-  else ctx_role<TM>(p, g - G_CTX0, sm);
+  constexpr int g_ctx0 = G_EN0 + N_EN * NC;
+  if (g < G_DEC0) att_role<NC>(p, g, sm);
+  else if (g < G_PROJ0) dec_role<NC>(p, g - G_DEC0, sm);
+  else if (g < G_EN0) proj_role<NC>(p, g - G_PROJ0, sm);
+  else if constexpr (NC == 1) {
+    if (g < g_ctx0) energy_role<TM>(p, g - G_EN0, sm);
+    else ctx_role<TM>(p, g - g_ctx0, sm);
+  } else {
+    if (g < g_ctx0) energy_long_role<NC>(p, g - G_EN0, sm);
+    else ctx_long_role<NC>(p, g - g_ctx0, sm);
+  }
 }
 
-constexpr size_t LDS_ATT = (size_t)(LDS_W + PD + QD + ED + 16 + 8) * sizeof(float);
-constexpr size_t LDS_DEC = (size_t)(LDS_W + DD + QD + ED + 8 + 8) * sizeof(float);
+constexpr size_t LDS_ATT = (size_t)(LDS_W + PD + QD + NC_MAX * ED + 16 + 8) * sizeof(float);
+constexpr size_t LDS_DEC = (size_t)(LDS_W + DD + QD + NC_MAX * ED + 8 + 8) * sizeof(float);
 constexpr size_t LDS_EN = (size_t)(2 * LOCK * LOCF + 32 * LOCF + 32 + 2 * (TMAX + 32) + TMAX * (LOCF + 1) + QD + 32 +
                                    4 * TMAX + N_EN * TMAX + 8 + 8) * sizeof(float);
 constexpr size_t TEAM_LDS = LDS_ATT > LDS_DEC ? (LDS_ATT > LDS_EN ? LDS_ATT : LDS_EN) : (LDS_DEC > LDS_EN ? LDS_DEC : LDS_EN);
@@ -785,10 +1074,9 @@ int t2_team_create(const T2TeamWeights* w, hipStream_t st, t2_team** out) {
                 "pack_lstm_kernel's grid covers every image");
   pack_lstm_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(pp);
   TTSX_LAUNCH_CHECK();
-  TTSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(t2_team_kernel<128>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)TEAM_LDS));
-  TTSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(t2_team_kernel<256>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)TEAM_LDS));
+  for (const void* k : {reinterpret_cast<const void*>(t2_team_kernel<128, 1>), reinterpret_cast<const void*>(t2_team_kernel<256, 1>),
+                        reinterpret_cast<const void*>(t2_team_kernel<256, NC_MAX>)})
+    TTSX_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TEAM_LDS));
   TTSX_HIP(hipStreamSynchronize(st));
   on_fail.dismiss();
   *out = t;
@@ -818,7 +1106,7 @@ int t2_team_set_proj(t2_team* t, const float* rows_w, const float* rows_b, int r
 }
 
 bool t2_team_supports(const t2_team* t, int B, int T, int r) {
-  return t && B == 1 && T >= 1 && T <= TMAX && r >= 1 && r <= 2 && t->proj_r == r;
+  return t && B == 1 && T >= 1 && T <= NC_MAX * 256 && r >= 1 && r <= 2 && t->proj_r == r;
 }
 
 int t2_team_run(t2_team* t, const float* enc, const float* P, const int32_t* len, int T, int r, int max_steps,
@@ -839,10 +1127,13 @@ int t2_team_run(t2_team* t, const float* enc, const float* P, const int32_t* len
   p.T = T, p.r = r, p.S = max_steps, p.free_run = fixed_steps ? 0 : 1, p.norm = norm, p.thr = stop_threshold;
   void* args[] = {&p};
   // cooperative: the launch is refused, not hung, if 216 workgroups of this size cannot be resident together
-  // (the attention roles are built for 128 and for 256 positions: a thread owns one position either way)
-  const void* kernel = T <= 128 ? reinterpret_cast<const void*>(t2_team_kernel<128>)
-                                : reinterpret_cast<const void*>(t2_team_kernel<256>);
-  TTSX_HIP(hipLaunchCooperativeKernel(kernel, dim3(G_TOTAL), dim3(NT), args, (unsigned)TEAM_LDS, st));
+  // (attention roles for 128 and for 256 positions, a thread owning one position either way; beyond that, four
+  // chunks of 256 positions with four energy and four context workgroups each)
+  const void* kernel = T <= 128   ? reinterpret_cast<const void*>(t2_team_kernel<128, 1>)
+                       : T <= 256 ? reinterpret_cast<const void*>(t2_team_kernel<256, 1>)
+                                  : reinterpret_cast<const void*>(t2_team_kernel<256, NC_MAX>);
+  const int grid = G_EN0 + 2 * N_EN * (T <= 256 ? 1 : NC_MAX);
+  TTSX_HIP(hipLaunchCooperativeKernel(kernel, dim3(grid), dim3(NT), args, (unsigned)TEAM_LDS, st));
   int32_t host[2] = {0, 0};
   TTSX_HIP(hipMemcpyAsync(&host[0], n_steps, sizeof(int32_t), hipMemcpyDeviceToHost, st));
   TTSX_HIP(hipMemcpyAsync(&host[1], t->abort_word, sizeof(int), hipMemcpyDeviceToHost, st));
