@@ -469,9 +469,10 @@ def main():
                                          "algorithmic bytes; the weights do not move)"}
         # the same decode as a chain of launches (what batch 2 and up, and texts beyond 128 symbols, run)
         model.set_team(0)
-        wl1.run()
-        wl1.run(record=True)
-        out["batch1"]["launch_chain_decoder_us_per_step"] = wl1.stages()["decoder"] * 1e3 / S
+        wlc = Workload(model, ap, ids1, S, ph1)
+        wlc.run()
+        wlc.run(record=True)
+        out["batch1"]["launch_chain_decoder_us_per_step"] = wlc.stages()["decoder"] * 1e3 / S
         model.set_team(-1)
         out["batch1_stop_driven"] = batch1_stop_driven(dev, ap)
         import contextlib

@@ -26,9 +26,12 @@ dst = os.environ.get("PROFILE_DST", os.path.join(ROOT, "profiles"))
 os.makedirs(dst, exist_ok=True)
 
 
+STEP_KERNELS = ("dual_kernel", "triple_kernel")  # the launches of a decoder step
+
+
 def short(name):
     name = name.replace("(anonymous namespace)::", "").replace("void ", "")
-    return name.split("(")[0] if name.startswith("dual_kernel") or name.startswith("gl_fused") else name[:100]
+    return name.split("(")[0] if name.startswith(STEP_KERNELS) or name.startswith("gl_fused") else name[:100]
 
 
 def counters(subdir):
@@ -62,7 +65,7 @@ if os.path.exists(log):
 fetch, write = counters("dec_FETCH_SIZE"), counters("dec_WRITE_SIZE")
 rows, total = [], 0.0
 for k in sorted(fetch, key=lambda k: -fetch[k]["FETCH_SIZE"][1]):
-    if not k.startswith("dual_kernel"):
+    if not k.startswith(STEP_KERNELS):
         continue
     n, f = fetch[k]["FETCH_SIZE"]
     w = write.get(k, {}).get("WRITE_SIZE", [n, 0.0])[1]
@@ -87,7 +90,7 @@ if sq:
     with open(os.path.join(dst, tag + "_decoder_sq.csv"), "w") as f:
         f.write("kernel,dispatches," + ",".join(n + "_per_dispatch" for n in names) + "\n")
         for k in sorted(sq, key=lambda k: -sq[k].get("SQ_BUSY_CYCLES", [0, 0])[1]):
-            if k.startswith("dual_kernel"):
+            if k.startswith(STEP_KERNELS):
                 n = max(v[0] for v in sq[k].values())
                 f.write('"%s",%d,' % (k, n) + ",".join("%.0f" % (sq[k][c][1] / max(sq[k][c][0], 1)) for c in names) + "\n")
     print("wrote decoder sq")

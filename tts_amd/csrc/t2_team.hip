@@ -26,7 +26,8 @@
 // x1 | x2 | h_a | partial energies | context | h_d.  Everything that depends on the previous step only (the
 // recurrent columns of both LSTMs, the location features) is evaluated while the chain is elsewhere.
 // A free run ends through the data: the workgroup that owns the stop row marks the words it publishes, and every
-// workgroup that sees a marked word marks what it publishes and leaves.  Every wait is bounded.
+// workgroup that sees a marked word marks what it publishes and leaves.  Every wait is bounded: a team that is not
+// resident together (other kernels hold CUs) raises an abort word after ~2 s and the host reports it.
 #include <algorithm>
 #include <vector>
 
@@ -1125,15 +1126,16 @@ int t2_team_run(t2_team* t, const float* enc, const float* P, const int32_t* len
   p.abort_word = t->abort_word, p.mel = mel, p.align = align, p.stop = stop, p.n_steps = n_steps;
   if (state_out) p.st = *state_out;
   p.T = T, p.r = r, p.S = max_steps, p.free_run = fixed_steps ? 0 : 1, p.norm = norm, p.thr = stop_threshold;
-  void* args[] = {&p};
-  // cooperative: the launch is refused, not hung, if 216 workgroups of this size cannot be resident together
   // (attention roles for 128 and for 256 positions, a thread owning one position either way; beyond that, four
   // chunks of 256 positions with four energy and four context workgroups each)
-  const void* kernel = T <= 128   ? reinterpret_cast<const void*>(t2_team_kernel<128, 1>)
-                       : T <= 256 ? reinterpret_cast<const void*>(t2_team_kernel<256, 1>)
-                                  : reinterpret_cast<const void*>(t2_team_kernel<256, NC_MAX>);
+  // A plain launch: every workgroup takes a whole CU (512 threads x 256 registers), the team is smaller than the
+  // chip, and every wait is bounded.  (A cooperative launch would refuse a team that cannot be resident, but
+  // rocprofv3's kernel trace crashes at exit in a process that has made one.)
   const int grid = G_EN0 + 2 * N_EN * (T <= 256 ? 1 : NC_MAX);
-  TTSX_HIP(hipLaunchCooperativeKernel(kernel, dim3(grid), dim3(NT), args, (unsigned)TEAM_LDS, st));
+  if (T <= 128) t2_team_kernel<128, 1><<<grid, NT, TEAM_LDS, st>>>(p);
+  else if (T <= 256) t2_team_kernel<256, 1><<<grid, NT, TEAM_LDS, st>>>(p);
+  else t2_team_kernel<256, NC_MAX><<<grid, NT, TEAM_LDS, st>>>(p);
+  TTSX_LAUNCH_CHECK();
   int32_t host[2] = {0, 0};
   TTSX_HIP(hipMemcpyAsync(&host[0], n_steps, sizeof(int32_t), hipMemcpyDeviceToHost, st));
   TTSX_HIP(hipMemcpyAsync(&host[1], t->abort_word, sizeof(int), hipMemcpyDeviceToHost, st));
