@@ -139,6 +139,29 @@ def cpu_baseline(sd, T_in, sample_steps, r):
                 model_s=t1 - t0, vocoder_s=t2 - t1, wav_rms=float(np.sqrt(np.mean(wav ** 2))))
 
 
+def cpu_config1():
+    """The CPU oracle on the stop-driven batch-1 request of `batch1_stop_driven` (T_in = 100, the late-stop
+    checkpoint, about 308 decoder steps): latency end to end with the model / vocoder split."""
+    from oracle import audio_oracle as ao
+    from oracle import t2_oracle
+    from tts_amd import synthetic
+    sd = synthetic.t2_state_dict(seed=0, prenet_type="bn", gains=synthetic.T2_LATE_STOP_GAINS)
+    ids = synthetic.t2_text_ids(99, 1, 100)
+    orc_ap = ao.AudioOracle(**ao.T2_AUDIO)
+    inv = orc_ap.inv_mel_basis()
+    t0 = time.perf_counter()
+    out = t2_oracle.inference(sd, ids, r=1, attn_norm="sigmoid", prenet_type="bn", max_steps=3000)
+    t1 = time.perf_counter()
+    mel = out["postnet_output"][0].numpy().T
+    wav = orc_ap.inv_mel_spectrogram(mel, synthetic.gl_init_phase(1, 1025, mel.shape[1]), inv)
+    t2 = time.perf_counter()
+    n = int(out["n_steps"][0])
+    return dict(workload="B=1, T_in=100, stop-driven (threshold 0.7), r=1: encoder + decoder + postnet, then 60-iter "
+                         "Griffin-Lim", n_steps=n, latency_s=t2 - t0, model_s=t1 - t0, vocoder_s=t2 - t1,
+                frames_per_s=mel.shape[1] / (t2 - t0), cores=int(torch.get_num_threads()), kind="port",
+                wav_rms=float(np.sqrt(np.mean(wav ** 2))))
+
+
 def tacotron_v1_batch1(dev, T_in=100, steps=200):
     """The Tacotron (CBHG postnet, linear spectrogram) configuration at batch 1: embedding -> encoder CBHG ->
     greedy decoder -> post-CBHG + last_linear -> 60-iteration Griffin-Lim (win 1102, reflect padding)."""
@@ -505,6 +528,8 @@ def main():
             torch.set_num_threads(nt)
         out["cpu_baseline"]["one_thread"] = {"value": one["value"], "unit": one["unit"], "cores": 1,
                                              "sample": one["sample"]}
+        # the batch-1 request of `batch1_stop_driven` on the host cores (latency, not a throughput sample)
+        out["cpu_baseline"]["config1_stop_driven"] = cpu_config1()
     else:
         out["cpu_baseline"] = None
     if rank == 0:

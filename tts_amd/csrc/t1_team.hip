@@ -785,6 +785,13 @@ int t1_team_create(const T1StepWeights* w, hipStream_t st, t1_team** out) {
   TTSX_ARG(w && out, "t1_team_create: null argument");
   *out = nullptr;
   if (w->mem_dim != MEM || w->odim != ODIM) return TTSX_OK;
+  {
+    // every workgroup of a team needs a CU of its own at the same time (two utterances: two teams)
+    int dev = 0, cus = 0;
+    TTSX_HIP(hipGetDevice(&dev));
+    TTSX_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    if (cus < 2 * TEAM) return TTSX_OK;
+  }
   t1_team* t = new t1_team();
   memset(t, 0, sizeof(*t));
   float *wc = nullptr, *bc = nullptr;

@@ -1051,6 +1051,14 @@ int t2_team_create(const T2TeamWeights* w, hipStream_t st, t2_team** out) {
   TTSX_ARG(w && out, "t2_team_create: null argument");
   *out = nullptr;
   if (!(w->query_w && w->v_w && w->v_b)) return TTSX_OK;  // (a decoder with another attention type)
+  {
+    // every workgroup of a team needs a CU of its own at the same time: no team on a device (or partition) with
+    // fewer CUs than the largest team
+    int dev = 0, cus = 0;
+    TTSX_HIP(hipGetDevice(&dev));
+    TTSX_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    if (cus < G_EN0 + 2 * N_EN * NC_MAX) return TTSX_OK;
+  }
   t2_team* t = new t2_team();
   memset(t, 0, sizeof(*t));
   ScopeExit on_fail([&] { t2_team_destroy(t); });
