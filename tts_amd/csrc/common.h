@@ -5,12 +5,15 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <mutex>
+
 #include "../../include/ttsx.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 void ttsx_set_error(const char* fmt, ...);
+std::mutex& ttsx_team_mutex();  // serialises the persistent team kernels of a process (errors.cpp)
 
 #define TTSX_HIP(expr)                                                                     \
   do {                                                                                     \

@@ -2,6 +2,8 @@
 #include <stdarg.h>
 #include <stdio.h>
 
+#include <mutex>
+
 #include "../../include/ttsx.h"
 
 static thread_local char g_err[512] = "no error";
@@ -15,3 +17,12 @@ void ttsx_set_error(const char* fmt, ...) {
 
 extern "C" const char* ttsx_last_error_string(void) { return g_err; }
 extern "C" int ttsx_version(void) { return 1; }
+
+// One team kernel at a time per process: a team needs most of the chip's CUs resident together, and two teams that
+// were dispatched into each other would both wait for CUs the other holds until their bounded waits give up.
+// Held from the launch until the run's stream synchronisation.  (Per process, not per device: the launches of two
+// GPUs do not compete, but a request thread holds the lock for a few milliseconds at most.)
+std::mutex& ttsx_team_mutex() {
+  static std::mutex m;
+  return m;
+}

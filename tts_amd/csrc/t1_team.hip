@@ -29,6 +29,7 @@
 // Every workgroup, the attention one included, evaluates the stop rule of a step itself from the published
 // frames (same instructions, same result), so the team leaves the loop together.  Every wait is bounded: a wave
 // that sees no progress for ~2 s raises an abort word that ends all other waits, and the host reports it.
+#include <mutex>
 #include <vector>
 
 #include "common.h"
@@ -853,6 +854,7 @@ int t1_team_run(t1_team* t, const float* enc, const float* annot, const int32_t*
 #endif
     t->cap_B = B;
   }
+  std::lock_guard<std::mutex> one_team(ttsx_team_mutex());  // until the synchronisation below
   // tags start at 1: all-zero words match no step
   TTSX_HIP(hipMemsetAsync(t->xch, 0, sizeof(u64) * (size_t)B * X_TEAM, st));
   TTSX_HIP(hipMemsetAsync(t->abort_word, 0, sizeof(int), st));

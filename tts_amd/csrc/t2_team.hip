@@ -29,6 +29,7 @@
 // workgroup that sees a marked word marks what it publishes and leaves.  Every wait is bounded: a team that is not
 // resident together (other kernels hold CUs) raises an abort word after ~2 s and the host reports it.
 #include <algorithm>
+#include <mutex>
 #include <vector>
 
 #include "common.h"
@@ -1160,6 +1161,7 @@ int t2_team_run(t2_team* t, const float* enc, const float* P, const int32_t* len
   TTSX_ARG(t && enc && P && len && mel && align && stop && n_steps, "t2_team_run: null argument");
   TTSX_ARG(t2_team_supports(t, 1, T, r), "t2_team_run: T=%d r=%d outside what the team kernel covers", T, r);
   TTSX_ARG(max_steps >= 1, "t2_team_run: max_steps=%d", max_steps);
+  std::lock_guard<std::mutex> one_team(ttsx_team_mutex());  // until the synchronisation below
   // tags start at 1: all-zero words match no step
   TTSX_HIP(hipMemsetAsync(t->xch, 0, sizeof(u64) * 2 * X_PAR, st));
   TTSX_HIP(hipMemsetAsync(t->abort_word, 0, sizeof(int), st));
