@@ -376,7 +376,11 @@ __global__ __launch_bounds__(64 * FR_PER_WG, 3) void frame_kernel(FrameP p) {
 // [i*hop, i*hop + win).  After round j every position below (4j+4)*hop has received all its
 // frames: those 4*hop positions are normalised and written, the next win-hop positions become the
 // carry.  Sums run in increasing frame order from zero, as the reference's frame-by-frame
-// accumulation does.  The run is preceded by `n_halo` rounds that only rebuild the carry.
+// accumulation does.  The run is preceded by `n_halo` rounds that only rebuild the carry - or, with one round per
+// workgroup, the carry comes from the left neighbour of the same launch: the carry a round leaves behind holds
+// its own frames only (carry_len <= 4 hop), summed from zero in frame order, so it is the same bits either way.
+// A workgroup publishes before it waits and its neighbour has the lower block index (dispatched first): no
+// wait can be circular.
 // PADDED = 1: out[b][g] over the centre-padded signal (what the next iteration reads; the zero
 // pad of 'constant' mode is written too); PADDED = 0: out[b][m] = trimmed signal.
 struct FusedP {
@@ -384,6 +388,11 @@ struct FusedP {
   float* out;
   int C, n_halo, n_rounds;  // rounds per workgroup, halo rounds, rounds per utterance
   int carry_len;            // win - hop
+  // One round per workgroup (small workloads, where the halo round would double the work): no halo; a workgroup
+  // publishes the carry its frames leave behind as tagged words [b][x][carry_len] and takes the carry of its left
+  // neighbour from there.  Null: halo rounds.
+  unsigned long long* xbuf;
+  unsigned xtag;            // this launch's tag (never repeats on a handle)
 };
 
 template <int KIND, int PADDED>
@@ -426,7 +435,8 @@ __global__ __launch_bounds__(64 * FR_PER_WG, 3) void gl_fused_kernel(FusedP P) {
   }
   const float inv_hop = 1.0f / (float)q.hop;
   int cur = 0;
-  for (int j = j_first - P.n_halo; j < j_end; ++j) {
+  const bool xmode = P.xbuf != nullptr;
+  for (int j = j_first - (xmode ? 0 : P.n_halo); j < j_end; ++j) {
     if (j < 0) continue;  // uniform: nothing before the first frame
     __syncthreads();      // tables / carry ready; the previous round's combine has read the frames
     const int i = FR_PER_WG * j + wave;
@@ -436,69 +446,114 @@ __global__ __launch_bounds__(64 * FR_PER_WG, 3) void gl_fused_kernel(FusedP P) {
     const float* c_old = s_carry + cur * P.carry_len;
     float* c_new = s_carry + (cur ^ 1) * P.carry_len;
     const int n_out = FR_PER_WG * q.hop;
-    const bool emit = j >= j_first;
-    // U positions per thread at a time: their LDS reads (carry + one sample of each of the four frames, clamped
-    // indices, selected afterwards) are all issued before the first use
-    constexpr int U = 4, NT = 64 * FR_PER_WG;
+    constexpr int NT = 64 * FR_PER_WG;
     const int n_tot = n_out + P.carry_len;
+    // emit: the round's own 4 hop positions are finished and written; carry_part: the positions behind them
+    // become the next carry
+    auto combine = [&](const bool emit, const bool carry_part) {
+      // U positions per thread at a time: their LDS reads (carry + one sample of each of the four frames, clamped
+      // indices, selected afterwards) are all issued before the first use
+      constexpr int U = 4;
+      const int t_end = carry_part ? n_tot : n_out;
 #pragma unroll 1
-    for (int t0 = emit ? 0 : (n_out / NT) * NT; t0 < n_tot; t0 += NT * U) {
-      float a[U][FR_PER_WG + 1];
+      for (int t0 = emit ? 0 : (n_out / NT) * NT; t0 < t_end; t0 += NT * U) {
+        float a[U][FR_PER_WG + 1];
 #pragma unroll
-      for (int x = 0; x < U; ++x) {
-        const int t = t0 + NT * x + tid;
-        a[x][0] = c_old[max(min(t, P.carry_len - 1), 0)];
+        for (int x = 0; x < U; ++x) {
+          const int t = t0 + NT * x + tid;
+          a[x][0] = c_old[max(min(t, P.carry_len - 1), 0)];
 #pragma unroll
-        for (int w = 0; w < FR_PER_WG; ++w)
-          a[x][1 + w] = reinterpret_cast<const float*>(s_data[w])[max(min(t - w * q.hop, q.win - 1), 0) + shift];
-      }
-#pragma unroll
-      for (int x = 0; x < U; ++x) {
-        const int t = t0 + NT * x + tid;
-        if (t >= n_tot || (!emit && t < n_out)) continue;
-        float acc = t < P.carry_len ? a[x][0] : 0.f;
-#pragma unroll
-        for (int w = 0; w < FR_PER_WG; ++w) {
-          const int n = t - w * q.hop;
-          acc += (n >= 0 && n < q.win && FR_PER_WG * j + w < Fb) ? a[x][1 + w] : 0.f;
+          for (int w = 0; w < FR_PER_WG; ++w)
+            a[x][1 + w] = reinterpret_cast<const float*>(s_data[w])[max(min(t - w * q.hop, q.win - 1), 0) + shift];
         }
-        if (t >= n_out) {
-          c_new[t - n_out] = acc;
-          continue;
-        }
-        const int a_pos = FR_PER_WG * j * q.hop + t;
-        const int g = q.lpad + a_pos, m = g - NFFT / 2;
-        float y = 0.f;
-        if (m >= 0 && m < L) {
-          // window sum-square over the frames that exist at this position
-          const int th = (int)(((float)t + 0.5f) * inv_hop);  // t / hop (exact: the quotient is below 16)
-          const int sl = FR_PER_WG * j + th;
-          const int u = t0 / NT + x;
-          float wss = 0.f;
-          if (u < WSS_U && sl >= K - 1 && sl < Fb) {
-            // (a select chain, not an index: keeps the table in registers)
-            wss = u == 0 ? wss_full[0] : u == 1 ? wss_full[1] : u == 2 ? wss_full[2] : u == 3 ? wss_full[3] : wss_full[4];
-          } else {
-            const int rho = t - th * q.hop;
 #pragma unroll
-            for (int kk = OLA_MAXK - 1; kk >= 0; --kk) {
-              const int fi = sl - kk, n = kk * q.hop + rho;
-              if (kk < K && fi >= 0 && fi < Fb && n < q.win) {
-                const float w = p.winpad[q.lpad + n];
-                wss += w * w;
+        for (int x = 0; x < U; ++x) {
+          const int t = t0 + NT * x + tid;
+          if (t >= t_end || (!emit && t < n_out)) continue;
+          float acc = t < P.carry_len ? a[x][0] : 0.f;
+#pragma unroll
+          for (int w = 0; w < FR_PER_WG; ++w) {
+            const int n = t - w * q.hop;
+            acc += (n >= 0 && n < q.win && FR_PER_WG * j + w < Fb) ? a[x][1 + w] : 0.f;
+          }
+          if (t >= n_out) {
+            c_new[t - n_out] = acc;
+            continue;
+          }
+          const int a_pos = FR_PER_WG * j * q.hop + t;
+          const int g = q.lpad + a_pos, m = g - NFFT / 2;
+          float y = 0.f;
+          if (m >= 0 && m < L) {
+            // window sum-square over the frames that exist at this position
+            const int th = (int)(((float)t + 0.5f) * inv_hop);  // t / hop (exact: the quotient is below 16)
+            const int sl = FR_PER_WG * j + th;
+            const int u = t0 / NT + x;
+            float wss = 0.f;
+            if (u < WSS_U && sl >= K - 1 && sl < Fb) {
+              // (a select chain, not an index: keeps the table in registers)
+              wss = u == 0 ? wss_full[0] : u == 1 ? wss_full[1] : u == 2 ? wss_full[2] : u == 3 ? wss_full[3] : wss_full[4];
+            } else {
+              const int rho = t - th * q.hop;
+#pragma unroll
+              for (int kk = OLA_MAXK - 1; kk >= 0; --kk) {
+                const int fi = sl - kk, n = kk * q.hop + rho;
+                if (kk < K && fi >= 0 && fi < Fb && n < q.win) {
+                  const float w = p.winpad[q.lpad + n];
+                  wss += w * w;
+                }
               }
             }
+            y = wss > 1.17549435e-38f ? acc / wss : acc;
           }
-          y = wss > 1.17549435e-38f ? acc / wss : acc;
-        }
-        if (PADDED) {
-          if (g < q.LP) P.out[(size_t)b * q.LP + g] = y;
-        } else {
-          if (m >= 0 && m < Lmax) P.out[(size_t)b * Lmax + m] = y;
+          if (PADDED) {
+            if (g < q.LP) P.out[(size_t)b * q.LP + g] = y;
+          } else {
+            if (m >= 0 && m < Lmax) P.out[(size_t)b * Lmax + m] = y;
+          }
         }
       }
+    };
+    if (!xmode) {
+      combine(j >= j_first, true);
+      cur ^= 1;
+      continue;
     }
-    cur ^= 1;
+    // ---- one round per workgroup: what the frames leave behind goes to the right neighbour, the carry comes
+    // from the left one (zero for the first round of an utterance)
+    typedef unsigned long long u64;
+    combine(false, true);
+    __syncthreads();
+    u64* mine = P.xbuf + ((size_t)b * gridDim.x + blockIdx.x) * P.carry_len;
+    for (int k = tid; k < P.carry_len; k += NT)
+      __hip_atomic_store(mine + k, ((u64)P.xtag << 32) | __float_as_uint(c_new[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    float* c_in = s_carry + cur * P.carry_len;
+    if (blockIdx.x == 0) {
+      for (int k = tid; k < P.carry_len; k += NT) c_in[k] = 0.f;
+    } else {
+      const u64* left = mine - P.carry_len;
+      constexpr int XU = (WP + NT - 1) / NT;  // carry_len < win <= WP
+      for (long spin = 0;; ++spin) {
+        u64 v[XU];
+        bool ok = true;
+#pragma unroll
+        for (int m = 0; m < XU; ++m) {
+          const int k = tid + NT * m;
+          v[m] = __hip_atomic_load(left + min(k, P.carry_len - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok = ok && (k >= P.carry_len || (unsigned)(v[m] >> 32) == P.xtag);
+        }
+        // (the left neighbour was dispatched before this workgroup and publishes before it waits; the bound is
+        // a last resort that makes a broken run visible instead of hanging it)
+        if (__all(ok) || spin > 40000000) {
+#pragma unroll
+          for (int m = 0; m < XU; ++m)
+            if (tid + NT * m < P.carry_len) c_in[tid + NT * m] = ok ? __uint_as_float((unsigned)v[m]) : __builtin_nanf("");
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
+    __syncthreads();
+    combine(true, false);
   }
   if (PADDED) {
     // the first lpad samples and the tail beyond the last round belong to nobody's slot
@@ -787,35 +842,58 @@ int check_gl_args(const float* mag, const float* init_phase, const float* wav, i
 // ping-ponging between the two padded signals ybuf[0] / ybuf[1] (B * q.LP floats each), de-emphasis into wav.
 // Every padded position of an utterance is written by each launch before the next one reads it, so the buffers
 // need not be cleared.  Nothing here allocates or synchronises.
+// How a run is cut into workgroups.
+struct GlPlan {
+  int n_rounds, n_halo, carry_len, C;
+  bool exchange;      // one round per workgroup and the carry fits the neighbour scheme (see FusedP::xbuf)
+  size_t xbuf_words;  // carry words of such a launch
+};
+GlPlan gl_plan(const ttsx_stft_params* sp, int B, int F) {
+  const FrameGeom q = make_geom(sp, F);
+  const size_t Lmax = (size_t)sp->hop_length * (F - 1);
+  GlPlan pl{};
+  // slots that can hold signal samples: padded indices lpad .. n_fft/2 + Lmax; a round = 4 slots
+  const int n_slots = ceil_div(NFFT / 2 + (int)Lmax - q.lpad, q.hop);
+  pl.n_rounds = ceil_div(n_slots, FR_PER_WG);
+  pl.n_halo = ceil_div(ceil_div(q.win, q.hop) - 1, FR_PER_WG);
+  pl.carry_len = q.win - q.hop;
+  // rounds per workgroup: long runs amortise the halo, short ones fill the chip; as many workgroups as are
+  // resident at once (three per CU, bounded by LDS), so that no second, mostly empty wave of them runs
+  constexpr int WGS_PER_CU = 3, CUS = 256;
+  pl.C = std::max(1, ceil_div(pl.n_rounds, std::max(1, CUS * WGS_PER_CU / B)));
+  pl.exchange = pl.C == 1 && pl.n_halo >= 1 && pl.carry_len >= 1 && pl.carry_len <= FR_PER_WG * q.hop;
+  pl.xbuf_words = (size_t)B * pl.n_rounds * pl.carry_len;
+  return pl;
+}
+
+// `xbuf` / `xtag`: carry words and launch counter of a handle (null: always halo rounds).
 int enqueue_griffin_lim(const float2* tw, const float* winpad, float* const ybuf[2], const float* mag,
                         const float* init_phase, const int32_t* n_frames, int B, int F, const ttsx_stft_params* sp,
-                        int iters, float preemph, float* wav, hipStream_t st) {
+                        int iters, float preemph, float* wav, hipStream_t st, unsigned long long* xbuf = nullptr,
+                        unsigned* xtag = nullptr) {
   const FrameGeom q = make_geom(sp, F);
   const size_t Lmax = (size_t)sp->hop_length * (F - 1);
   FusedP P{};
   P.f.mag = mag, P.f.phase01 = init_phase, P.f.n_frames = n_frames, P.f.tw = tw, P.f.winpad = winpad;
   P.f.B = B, P.f.F = F, P.f.q = q;
-  // slots that can hold signal samples: padded indices lpad .. n_fft/2 + Lmax; a round = 4 slots
-  const int n_slots = ceil_div(NFFT / 2 + (int)Lmax - q.lpad, q.hop);
-  P.n_rounds = ceil_div(n_slots, FR_PER_WG);
-  P.n_halo = ceil_div(ceil_div(q.win, q.hop) - 1, FR_PER_WG);
-  P.carry_len = q.win - q.hop;
-  // rounds per workgroup: long runs amortise the halo, short ones fill the chip; as many workgroups as are
-  // resident at once (three per CU, bounded by LDS), so that no second, mostly empty wave of them runs
-  constexpr int WGS_PER_CU = 3, CUS = 256;
-  P.C = std::max(1, ceil_div(P.n_rounds, std::max(1, CUS * WGS_PER_CU / B)));
+  const GlPlan pl = gl_plan(sp, B, F);
+  P.n_rounds = pl.n_rounds, P.n_halo = pl.n_halo, P.carry_len = pl.carry_len, P.C = pl.C;
+  const bool exchange = pl.exchange && xbuf && xtag;
+  if (exchange) P.xbuf = xbuf;
   const dim3 grid(ceil_div(P.n_rounds, P.C), B), refl_grid(NFFT / 256, B);
   const size_t smem = 2 * (size_t)std::max(P.carry_len, 1) * sizeof(float);
   const bool reflect = sp->pad_mode == TTSX_PAD_REFLECT;
   const bool direct = preemph == 0.f;  // without de-emphasis the last launch writes the trimmed signal itself
   int cur = 0;
   P.out = (direct && iters == 0) ? wav : ybuf[cur];
+  if (exchange) P.xtag = ++*xtag;
   if (direct && iters == 0) gl_fused_kernel<K_GL_INIT, 0><<<grid, 64 * FR_PER_WG, smem, st>>>(P);
   else gl_fused_kernel<K_GL_INIT, 1><<<grid, 64 * FR_PER_WG, smem, st>>>(P);
   TTSX_LAUNCH_CHECK();
   for (int it = 0; it < iters; ++it) {
     if (reflect) reflect_pad_kernel<<<refl_grid, 256, 0, st>>>(ybuf[cur], n_frames, B, F, q);
     P.f.ypad = ybuf[cur];
+    if (exchange) P.xtag = ++*xtag;
     const bool last = it + 1 == iters;
     if (last && direct) {
       P.out = wav;
@@ -874,6 +952,11 @@ struct ttsx_vocoder {
   float* yw;       // windowed frames of the stand-alone ISTFT
   float* ypad;     // two padded signals back to back (an iteration reads one and writes the other)
   size_t cap_yw, cap_ypad;
+  // small workloads: carries handed from workgroup to workgroup inside a launch (FusedP::xbuf), as words tagged
+  // with a launch counter that never repeats between two clears of the buffer
+  unsigned long long* xbuf;
+  size_t cap_xbuf;
+  unsigned xtag;
 };
 
 namespace {
@@ -922,7 +1005,7 @@ extern "C" int ttsx_vocoder_create(const ttsx_stft_params* sp, void* stream, tts
 
 extern "C" int ttsx_vocoder_destroy(ttsx_vocoder* v) {
   if (!v) return TTSX_OK;
-  float* bufs[] = {reinterpret_cast<float*>(v->tw), v->winpad, v->yw, v->ypad};
+  float* bufs[] = {reinterpret_cast<float*>(v->tw), v->winpad, v->yw, v->ypad, reinterpret_cast<float*>(v->xbuf)};
   for (float* b : bufs)
     if (b) (void)hipFree(b);   // (hipFree waits for the device: nothing enqueued on the handle is cut short)
   delete v;
@@ -939,7 +1022,24 @@ extern "C" int ttsx_vocoder_griffin_lim(ttsx_vocoder* v, const float* mag, const
   const size_t n_pad = (size_t)B * make_geom(&v->sp, F).LP;
   if ((rc = grow(&v->ypad, &v->cap_ypad, 2 * n_pad, st))) return rc;
   float* const ybuf[2] = {v->ypad, v->ypad + n_pad};
-  return enqueue_griffin_lim(v->tw, v->winpad, ybuf, mag, init_phase, n_frames, B, F, &v->sp, iters, preemph, wav, st);
+  const GlPlan pl = gl_plan(&v->sp, B, F);
+  if (pl.exchange) {
+    const bool wrap = v->xtag > 0xfffffff0u - (unsigned)(iters + 1);
+    if (pl.xbuf_words > v->cap_xbuf || wrap) {
+      if (v->xbuf) {
+        TTSX_HIP(hipStreamSynchronize(st));
+        if (pl.xbuf_words > v->cap_xbuf) (void)hipFree(v->xbuf), v->xbuf = nullptr, v->cap_xbuf = 0;
+      }
+      if (!v->xbuf) {
+        TTSX_HIP(hipMalloc(reinterpret_cast<void**>(&v->xbuf), pl.xbuf_words * sizeof(unsigned long long)));
+        v->cap_xbuf = pl.xbuf_words;
+      }
+      TTSX_HIP(hipMemsetAsync(v->xbuf, 0, v->cap_xbuf * sizeof(unsigned long long), st));  // tag 0 matches no launch
+      v->xtag = 0;
+    }
+  }
+  return enqueue_griffin_lim(v->tw, v->winpad, ybuf, mag, init_phase, n_frames, B, F, &v->sp, iters, preemph, wav, st,
+                             pl.exchange ? v->xbuf : nullptr, &v->xtag);
 }
 
 extern "C" int ttsx_vocoder_stft(ttsx_vocoder* v, const float* y, int B, int F, float* spec_re, float* spec_im,
