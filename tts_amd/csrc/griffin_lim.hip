@@ -25,8 +25,33 @@
 #include <vector>
 
 #include "common.h"
+#include "pk_complex.h"
 
 namespace {
+
+// Tuning builds (-DTTSX_GL_TIMING): wave 0 of one workgroup in the middle of the grid leaves 100 MHz timestamps
+// at the phase boundaries of one round (tools/gl_timing.py).
+#ifdef TTSX_GL_TIMING
+__device__ long long gl_marks[32];
+#define GL_MARK(i)                                                                \
+  do {                                                                            \
+    if (mark) {                                                                   \
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                 \
+      if (threadIdx.x == 0) gl_marks[i] = wall_clock64();                         \
+    }                                                                             \
+  } while (0)
+// (without waiting for the stores of the phase to be acknowledged)
+#define GL_MARK_NV(i)                                                             \
+  do {                                                                            \
+    if (mark) {                                                                   \
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                          \
+      if (threadIdx.x == 0) gl_marks[i] = wall_clock64();                         \
+    }                                                                             \
+  } while (0)
+#else
+#define GL_MARK(i) do { } while (0)
+#define GL_MARK_NV(i) do { } while (0)
+#endif
 
 constexpr int NFFT = 2048, MC = 1024, NBIN = 1025;
 constexpr int WP = 1104;          // row pitch of the windowed-frame buffer (floats)
@@ -41,6 +66,11 @@ __device__ __forceinline__ float2 cconj(float2 a) { return make_float2(a.x, -a.y
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 __device__ __forceinline__ int pidx(int i) { return i + (i >> 4); }
+// *(T*)((char*)base + byte_off) with a zero-extended 32-bit offset
+template <typename T>
+__device__ __forceinline__ T ld_at(const void* base, unsigned byte_off) {
+  return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
+}
 
 // 4-point DFT in place; SIGN = -1 forward, +1 inverse
 template <int SIGN>
@@ -88,7 +118,11 @@ __device__ __forceinline__ void dft16(float2 (&v)[16]) {
     }
 }
 
-// W_1024^m = exp(-2 pi i m / 1024) (m < 1024) from the LDS table; conjugated for the inverse
+// W_1024^m = exp(-2 pi i m / 1024) (m < TW_MAIN) from the LDS table; conjugated for the inverse.  Entries
+// TW_MAIN + 16 r + k hold W_256^(k r) (r, k < 16), the twiddles of the second radix-16 pass, in the order the lanes
+// read them: lanes with different k of one r hit consecutive words (read as W_1024^(4 k r) from the main table,
+// strides of 4 r entries put up to sixteen different addresses on one bank).
+constexpr int TW_MAIN = 768, TW_ALL = TW_MAIN + 256;
 template <int SIGN>
 __device__ __forceinline__ float2 tw1024(const float2* s_tw, int m) {
   const float2 w = s_tw[m];
@@ -112,7 +146,7 @@ __device__ __forceinline__ void fft1024_tail(float2 (&v)[16], float2* s, const f
   for (int r = 0; r < 16; ++r) v[r] = s[bl + 68 * r];
   const int k = lane & 15;
 #pragma unroll
-  for (int r = 1; r < 16; ++r) v[r] = cmul(v[r], tw1024<SIGN>(s_tw, 4 * k * r + z));
+  for (int r = 1; r < 16; ++r) v[r] = cmul(v[r], tw1024<SIGN>(s_tw, TW_MAIN + 16 * r + k + z));
   dft16<SIGN>(v);
   const int j0 = (lane >> 4) * 256 + k;
   const int bj = j0 + (j0 >> 4);  // pidx(j0 + 16 r) = bj + 17 r
@@ -172,9 +206,10 @@ struct FrameP {
 };
 
 __device__ __forceinline__ void load_tables(float2* s_tw, float2* s_tw2, const float2* tw, int tid) {
-  for (int i = tid; i < 1024; i += 64 * FR_PER_WG) {
-    const float2 w = tw[(2 * i) & 1023];  // W_1024^i = W_2048^(2i), and W_1024^(i+512) = -W_1024^i
-    s_tw[i] = i >= 512 ? make_float2(-w.x, -w.y) : w;
+  for (int i = tid; i < TW_ALL; i += 64 * FR_PER_WG) {
+    const int e = i < TW_MAIN ? i : (4 * ((i - TW_MAIN) & 15) * ((i - TW_MAIN) >> 4)) & 1023;
+    const float2 w = tw[(2 * e) & 1023];  // W_1024^e = W_2048^(2e), and W_1024^(e+512) = -W_1024^e
+    s_tw[i] = e >= 512 ? make_float2(-w.x, -w.y) : w;
   }
   for (int i = tid; i <= 512; i += 64 * FR_PER_WG) s_tw2[i] = tw[i];
 }
@@ -216,16 +251,29 @@ __device__ __forceinline__ void frame_body(const FrameP& p, int b, int i, float2
     if (KIND == K_GL_ITER || KIND == K_STFT) {
       // ---- analysis: z[m] = (x[2m], x[2m+1]) windowed, first radix-16 pass straight from HBM
       const float* src = p.ypad + (size_t)b * q.LP + (size_t)i * q.hop;
+      // second bases 4 KiB further on, opaque: the constant part of every address then fits the instruction offset
+      unsigned hi_off = 1024;
+      asm volatile("" : "+s"(hi_off));
+      const float* src_hi = src + hi_off;
+      const float2* win_hi = s_win2 + (hi_off >> 1);
 #pragma unroll
       for (int h = 0; h < 4; ++h) {
-        // four groups of loads, fenced so that at most one group's operands are live at a time
+        // four groups of loads, fenced so that at most one group's operands are live at a time and every load of a
+        // group has left before its first product waits
+        float2 w[4];
+        float x0[4], x1[4];
 #pragma unroll
-        for (int r = 4 * h; r < 4 * h + 4; ++r) {
-          const int m = lane_a + 64 * r;
-          const float2 w = s_win2[m + z];
+        for (int g = 0; g < 4; ++g) {
+          const int r = 4 * h + g;
+          // (uniform base + constant, then a 32-bit unsigned lane offset: the scalar-base addressing form)
+          w[g] = ld_at<float2>((r < 8 ? s_win2 : win_hi) + 64 * (r & 7), (unsigned)(lane_a + z) * 8u);
           // the hop is odd in general: two 4-byte loads
-          v[r] = make_float2(src[2 * m] * w.x, src[2 * m + 1] * w.y);
+          const float* sr = (r < 8 ? src : src_hi) + 128 * (r & 7);
+          x0[g] = ld_at<float>(sr, (unsigned)lane_a * 8u), x1[g] = ld_at<float>(sr + 1, (unsigned)lane_a * 8u);
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) v[4 * h + g] = make_float2(x0[g] * w[g].x, x1[g] * w[g].y);
         __builtin_amdgcn_sched_barrier(0);
       }
       dft16<-1>(v);
@@ -352,13 +400,257 @@ __device__ __forceinline__ void frame_body(const FrameP& p, int b, int i, float2
   }
 }
 
+// ---- The Griffin-Lim iteration's frame in packed arithmetic (pk_complex.h): the same transforms, LDS layout and
+// pass structure as frame_body, with every complex value in one register pair.  INV = inverse transform.
+template <bool INV>
+__device__ __forceinline__ void pdft4(f2& a, f2& b, f2& c, f2& d) {
+  const f2 s0 = a + c, d0 = a - c, s1 = b + d, d1 = b - d;
+  a = s0 + s1;
+  c = s0 - s1;
+  if (!INV) b = pk_addmj(d0, d1), d = pk_addpj(d0, d1);  // forward: b = d0 - i d1
+  else b = pk_addpj(d0, d1), d = pk_addmj(d0, d1);
+}
+
+template <bool INV>
+__device__ __forceinline__ void pdft16(f2 (&v)[16]) {
+#pragma unroll
+  for (int r1 = 0; r1 < 4; ++r1) pdft4<INV>(v[r1], v[r1 + 4], v[r1 + 8], v[r1 + 12]);
+  // W16^m at positive angle; the forward transform multiplies by the conjugates
+  constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, C2 = 0.70710678118654752f;
+  const f2 b1 = {C1, S1}, b2 = {C2, C2}, b3 = {S1, C1}, b6 = {-C2, C2}, b9 = {-C1, -S1};
+  v[1 + 4] = pk_cmulc<!INV>(v[1 + 4], b1);
+  v[2 + 4] = pk_cmulc<!INV>(v[2 + 4], b2);
+  v[3 + 4] = pk_cmulc<!INV>(v[3 + 4], b3);
+  v[1 + 8] = pk_cmulc<!INV>(v[1 + 8], b2);
+  v[2 + 8] = pk_mulj<!INV>(v[2 + 8]);
+  v[3 + 8] = pk_cmulc<!INV>(v[3 + 8], b6);
+  v[1 + 12] = pk_cmulc<!INV>(v[1 + 12], b3);
+  v[2 + 12] = pk_cmulc<!INV>(v[2 + 12], b6);
+  v[3 + 12] = pk_cmulc<!INV>(v[3 + 12], b9);
+#pragma unroll
+  for (int q2 = 0; q2 < 4; ++q2) pdft4<INV>(v[4 * q2], v[4 * q2 + 1], v[4 * q2 + 2], v[4 * q2 + 3]);
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = a + 1; b < 4; ++b) {
+      const f2 t = v[4 * a + b];
+      v[4 * a + b] = v[4 * b + a];
+      v[4 * b + a] = t;
+    }
+}
+
+// pass 2 and pass 3 (see fft1024_tail)
+template <bool INV>
+__device__ __forceinline__ void pfft1024_pass2(f2 (&v)[16], f2* s, const f2* s_tw, int lane, int z) {
+  const int bl = lane + (lane >> 4);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) s[17 * lane + r] = v[r];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) v[r] = s[bl + 68 * r];
+  const int k = lane & 15;
+#pragma unroll
+  for (int r = 1; r < 16; ++r) v[r] = pk_cmul<INV>(v[r], s_tw[TW_MAIN + 16 * r + k + z]);
+  pdft16<INV>(v);
+  const int j0 = (lane >> 4) * 256 + k;
+  const int bj = j0 + (j0 >> 4);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) s[bj + 17 * r] = v[r];
+}
+template <bool INV>
+__device__ __forceinline__ void pfft1024_pass3(f2 (&v)[16], f2* s, const f2* s_tw, int lane, int z) {
+  const int bl = lane + (lane >> 4);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[4 * i + r] = s[bl + 68 * i + 272 * r];
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int j = lane + 64 * i + z;
+    v[4 * i + 1] = pk_cmul<INV>(v[4 * i + 1], s_tw[j]);
+    v[4 * i + 2] = pk_cmul<INV>(v[4 * i + 2], s_tw[2 * j]);
+    v[4 * i + 3] = pk_cmul<INV>(v[4 * i + 3], s_tw[3 * j]);
+    pdft4<INV>(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+  }
+}
+
+// One Griffin-Lim iteration of one frame (utterance b, frame i) by one wave; the windowed synthesis frame (samples
+// lpad_even .. lpad_even + WP) is left in the wave's LDS region `s`, viewed as floats.
+// Factors of two are not applied where they fall: the analysis side works on 2 X (only its phase is used), the
+// synthesis side on 2 Z, and the target magnitudes carry 1/2 and the 1/1024 of the inverse transform (powers of two:
+// the same bits as scaling at the end).
+// The frame's input, requested one round ahead (frame_prefetch) so that the memory round trip (~2 us under load)
+// passes behind the overlap-add of the round before: x[r] = samples 2m, 2m+1 at m = lane + 64 r.
+struct FrameIn {
+  f2 x[16];
+};
+__device__ __forceinline__ void frame_prefetch(const FrameP& p, int b, int i, int lane, FrameIn& in) {
+  const FrameGeom q = p.q;
+  int lane_a = lane;
+  asm volatile("" : "+v"(lane_a));
+  __builtin_assume((unsigned)lane_a < 64u);
+  // second base 4 KiB further on: the constant part of every global address then fits the instruction offset
+  unsigned hi_off = 1024;
+  asm volatile("" : "+s"(hi_off));
+  const float* src = p.ypad + (size_t)b * q.LP + (size_t)i * q.hop;
+  const float* src_hi = src + hi_off;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    // (uniform base + constant, then a 32-bit unsigned lane offset: the scalar-base addressing form)
+    // the hop is odd in general: two 4-byte loads
+    const float* sr = (r < 8 ? src : src_hi) + 128 * (r & 7);
+    in.x[r].x = ld_at<float>(sr, (unsigned)lane_a * 8u), in.x[r].y = ld_at<float>(sr + 1, (unsigned)lane_a * 8u);
+  }
+}
+
+__device__ __forceinline__ void frame_iter(const FrameP& p, int b, int i, float2* s_, const float2* s_tw_,
+                                           const float2* s_tw2_, int lane, const FrameIn& in, bool mark) {
+  const FrameGeom q = p.q;
+  GL_MARK(0);
+  f2* s = reinterpret_cast<f2*>(s_);
+  const f2* s_tw = reinterpret_cast<const f2*>(s_tw_);
+  const f2* s_tw2 = reinterpret_cast<const f2*>(s_tw2_);
+  const f2* win2 = reinterpret_cast<const f2*>(p.winpad);
+  const size_t frow = (size_t)b * p.F + i;
+  int z = 0;
+  asm volatile("" : "+v"(z));  // opaque zero: pins loop-invariant table loads inside the loop
+  int lane_a = lane, lane_b = lane, lane_s = lane;
+  asm volatile("" : "+v"(lane_a), "+v"(lane_b), "+v"(lane_s));
+  __builtin_assume((unsigned)lane_a < 64u && (unsigned)lane_b < 64u && (unsigned)lane_s < 64u);
+  __builtin_assume((unsigned)z < 8u);
+  unsigned hi_off = 1024;
+  asm volatile("" : "+s"(hi_off));
+  const f2* win_hi = win2 + (hi_off >> 1);
+
+  // the window at this lane's samples first, then the target magnitudes of its bin pairs (k, 1024 - k), k = lane +
+  // 64 c: loads return in order, so the window products wait for the (cached) window only and the magnitudes, which
+  // come from HBM, land during the analysis transform
+  f2 w[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) w[r] = ld_at<f2>((r < 8 ? win2 : win_hi) + 64 * (r & 7), (unsigned)(lane_a + z) * 8u);
+  __builtin_amdgcn_sched_barrier(0);
+  f2 mg[8];
+  float m512;
+  {
+    const float* mg0 = p.mag + frow * NBIN;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      mg[c].x = ld_at<float>(mg0 + 64 * c, (unsigned)lane_a * 4u);
+      mg[c].y = ld_at<float>(mg0 + (MC - 63) - 64 * c, (unsigned)(63 - lane_a) * 4u);
+    }
+    m512 = mg0[MC / 2];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  f2 v[16];
+  {
+    // ---- analysis: z[m] = (x[2m], x[2m+1]) windowed, first radix-16 pass on the prefetched input
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = in.x[r] * w[r];
+    GL_MARK(1);
+    pdft16<false>(v);
+    pfft1024_pass2<false>(v, s, s_tw, lane_a, z);
+    pfft1024_pass3<false>(v, s, s_tw, lane_a, z);
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s[lane_a + (lane_a >> 4) + 68 * c + 272 * r] = v[4 * c + r];
+  }
+  GL_MARK(2);
+  constexpr float SCALE = 1.0f / MC;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) mg[c] *= 0.5f * SCALE;
+  m512 *= SCALE;
+
+  // ---- per-bin work on pairs (k, 1024-k); operands of the eight pairs first (one LDS latency, not eight)
+  f2 Zk8[8], Zm8[8], W8[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const int k = lane_b + 64 * c;
+    Zk8[c] = s[pidx(k)], Zm8[c] = s[pidx((MC - k) & (MC - 1))];
+    W8[c] = s_tw2[k + z];
+  }
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const int k = lane_b + 64 * c;
+    const f2 W = W8[c];
+    // real-transform post-pass: with E = (Zk + conj Zm)/2, D = (Zk - conj Zm)/2: X[k] = E - i W D,
+    // conj X[1024-k] = E + i W D
+    const f2 S = pk_addconj(Zk8[c], Zm8[c]), Dd = pk_subconj(Zk8[c], Zm8[c]);
+    const f2 P = pk_cmul<false>(Dd, W);
+    const f2 Xk = pk_addmj(S, P), Ym = pk_addpj(S, P);  // 2 X[k], 2 conj X[1024-k]
+    // unit phasors times the target magnitudes
+    const f2 qk = Xk * Xk, qm = Ym * Ym;
+    f2 ss;
+    ss.x = qk.x + qk.y, ss.y = qm.x + qm.y;
+    f2 Xk2, Ym2;
+    if (__builtin_expect(ss.x > 1e-30f && ss.x < 1e30f && ss.y > 1e-30f && ss.y < 1e30f, 1)) {
+      f2 n;
+      n.x = __builtin_amdgcn_rsqf(ss.x), n.y = __builtin_amdgcn_rsqf(ss.y);
+      n *= mg[c];
+      Xk2 = pk_scale_lo(Xk, n), Ym2 = pk_scale_hi(Ym, n);
+    } else {
+      // |X|^2 under- or overflows, or X = 0 (np.angle(0) = 0)
+      const float2 uk = unit_phase(make_float2(Xk.x, Xk.y)), um = unit_phase(make_float2(Ym.x, Ym.y));
+      Xk2 = (f2){uk.x, uk.y} * mg[c].x, Ym2 = (f2){um.x, um.y} * mg[c].y;
+    }
+    // inverse pre-pass: Z[k] = E' + i O', Z[1024-k] = conj(E' - i O') with E' = (X'k + Y'm)/2,
+    // O' = conj(W) (X'k - Y'm)/2
+    const f2 A = Xk2 + Ym2, Bd = Xk2 - Ym2;
+    const f2 O = pk_cmul<true>(Bd, W);
+    const f2 zk = pk_addpj(A, O), zm = pk_conj_addmj(A, O);
+    s[pidx(k)] = zk;
+    // (k = 0 has no partner slot: it stores its own value a second time, which keeps the store unconditional)
+    s[pidx(k ? MC - k : 0)] = k ? zm : zk;
+  }
+  if (lane_b == 0) {
+    // Bin 512 is its own partner and its twiddle is -i: X[512] = conj Z[512], Z'[512] = conj X'[512], so the new
+    // value is the old one's unit phasor times the magnitude
+    const f2 Z = s[pidx(512)];
+    const float2 u = unit_phase(make_float2(Z.x, Z.y));
+    s[pidx(512)] = (f2){u.x, u.y} * m512;
+  }
+
+  GL_MARK(3);
+  // ---- synthesis: inverse transform, window, windowed frame into the wave's LDS region
+#pragma unroll
+  for (int r = 0; r < 16; ++r) v[r] = s[lane_s + (lane_s >> 4) + 68 * r];
+  pdft16<true>(v);
+  pfft1024_pass2<true>(v, s, s_tw, lane_s, z);
+  // the window values of the sixteen sample pairs (always inside the table) are requested before the last pass
+  // and land during it
+  f2 wn[16];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      wn[4 * c + r] = ld_at<f2>((r < 2 ? win2 : win_hi) + 64 * c + 256 * (r & 1), (unsigned)(lane_s + z) * 8u);
+  __builtin_amdgcn_sched_barrier(0);
+  pfft1024_pass3<true>(v, s, s_tw, lane_s, z);
+  GL_MARK(4);
+  {
+    const int lpe = q.lpad & ~1;
+    // (all lanes have read their last pass from `s` before the first of these stores issues)
+    float* dst = reinterpret_cast<float*>(s);
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = lane_s + 64 * c + 256 * r;  // complex index -> samples 2m, 2m+1
+        const int n = 2 * m - lpe;
+        if (n >= 0 && n < WP) *reinterpret_cast<f2*>(dst + n) = v[4 * c + r] * wn[4 * c + r];
+      }
+  }
+  GL_MARK_NV(5);
+}
+
 // Frames strided over the grid, windowed synthesis frames to HBM (stand-alone STFT / ISTFT).
 template <int KIND>
 __global__ __launch_bounds__(64 * FR_PER_WG, 3) void frame_kernel(FrameP p) {
-  __shared__ float2 s_tw[1024];   // W_1024^m
+  __shared__ float2 s_tw[TW_ALL];  // W_1024^m and the second-pass table
   __shared__ float2 s_tw2[516];   // W_2048^k, k <= 512 (real-transform post/pre-processing)
   __shared__ float2 s_data[FR_PER_WG][LDS_PER_FR];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  // (the wave index through readfirstlane: frame index and row pointers are then wave-uniform for the compiler)
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   load_tables(s_tw, s_tw2, p.tw, tid);
   __syncthreads();
   const long total = (long)p.B * p.F;
@@ -397,7 +689,7 @@ struct FusedP {
 
 template <int KIND, int PADDED>
 __global__ __launch_bounds__(64 * FR_PER_WG, 3) void gl_fused_kernel(FusedP P) {
-  __shared__ float2 s_tw[1024];
+  __shared__ float2 s_tw[TW_ALL];
   __shared__ float2 s_tw2[516];
   __shared__ float2 s_data[FR_PER_WG][LDS_PER_FR];
   extern __shared__ float s_carry[];  // [2][carry_len]
@@ -436,12 +728,30 @@ __global__ __launch_bounds__(64 * FR_PER_WG, 3) void gl_fused_kernel(FusedP P) {
   const float inv_hop = 1.0f / (float)q.hop;
   int cur = 0;
   const bool xmode = P.xbuf != nullptr;
-  for (int j = j_first - (xmode ? 0 : P.n_halo); j < j_end; ++j) {
-    if (j < 0) continue;  // uniform: nothing before the first frame
+  const int j_start = max(j_first - (xmode ? 0 : P.n_halo), 0);  // (nothing before the first frame)
+  FrameIn fin;
+  if constexpr (KIND == K_GL_ITER) {
+    if (j_start < j_end && FR_PER_WG * j_start + wave < Fb) frame_prefetch(p, b, FR_PER_WG * j_start + wave, lane, fin);
+  }
+  for (int j = j_start; j < j_end; ++j) {
     __syncthreads();      // tables / carry ready; the previous round's combine has read the frames
     const int i = FR_PER_WG * j + wave;
-    if (i < Fb) frame_body<KIND, true>(p, b, i, s_data[wave], s_tw, s_tw2, lane);
+#ifdef TTSX_GL_TIMING
+    const bool mark = KIND == K_GL_ITER && blockIdx.x == gridDim.x / 2 && blockIdx.y == gridDim.y / 2 && j == j_first + 1;
+#else
+    constexpr bool mark = false;
+#endif
+    if (i < Fb) {
+      if constexpr (KIND == K_GL_ITER) frame_iter(p, b, i, s_data[wave], s_tw, s_tw2, lane, fin, mark);
+      else frame_body<KIND, true>(p, b, i, s_data[wave], s_tw, s_tw2, lane);
+    }
+    if constexpr (KIND == K_GL_ITER) {
+      // the next round's input: in flight across the overlap-add below
+      __builtin_amdgcn_sched_barrier(0);  // (not hoisted into the frame code, where registers are scarce)
+      if (j + 1 < j_end && i + FR_PER_WG < Fb) frame_prefetch(p, b, i + FR_PER_WG, lane, fin);
+    }
     __syncthreads();
+    GL_MARK_NV(6);
     // ---- combine: positions t = a - 4j*hop in [0, 4*hop + carry_len)
     const float* c_old = s_carry + cur * P.carry_len;
     float* c_new = s_carry + (cur ^ 1) * P.carry_len;
@@ -516,6 +826,7 @@ __global__ __launch_bounds__(64 * FR_PER_WG, 3) void gl_fused_kernel(FusedP P) {
     if (!xmode) {
       combine(j >= j_first, true);
       cur ^= 1;
+      GL_MARK_NV(7);
       continue;
     }
     // ---- one round per workgroup: what the frames leave behind goes to the right neighbour, the carry comes
@@ -1177,3 +1488,9 @@ extern "C" int ttsx_griffin_lim_noalloc(const float* mag, const float* init_phas
   float* const ybuf[2] = {base + NOALLOC_TABLE_FLOATS, base + NOALLOC_TABLE_FLOATS + n_pad};
   return enqueue_griffin_lim(tw, winpad, ybuf, mag, init_phase, n_frames, B, F, sp, iters, preemph, wav, st);
 }
+
+#ifdef TTSX_GL_TIMING
+extern "C" int ttsx_debug_gl_timing(long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(gl_marks), sizeof(long long) * 32) == hipSuccess ? 0 : 1;
+}
+#endif
