@@ -26,6 +26,7 @@ The JSON line also carries
   roofline      the decoder step (the dominant stage) against the chip's fp32-MFMA / HBM peak,
                 from HIP-event timing on the launch stream inside this run;
   roofline_gl   the Griffin-Lim stage against the HBM and vector-ALU peaks;
+  roofline_postnet / roofline_encoder   the conv stacks (and the encoder BiLSTM) against the fp32-MFMA peak;
   cpu_baseline  the CPU oracle (a restatement of the reference's PyTorch/NumPy path) timed on
                 this box's host cores on a bounded sample of the same workload (rank 0, N=1);
   batch1        batch-1 latency and real-time factor of the same path, fixed 800 steps;
@@ -466,6 +467,23 @@ def main():
                             "valu": {"achieved": n_fr * GL_FLOPS_PER_FRAME / gl_s / 1e12,
                                      "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                      "frac": n_fr * GL_FLOPS_PER_FRAME / gl_s / 1e12 / MFMA_F32_PEAK_TFLOPS}})
+
+    # the two conv stacks on the MFMA conv engine: postnet 80 -> 512 -> 512 -> 512 -> 512 -> 80 and the three
+    # 512 -> 512 encoder blocks, five taps each (2 flops per multiply-add); the encoder stage also holds the BiLSTM
+    post_flops = n_fr * 2.0 * 5 * (80 * 512 + 3 * 512 * 512 + 512 * 80)
+    enc_conv_flops = B * T * 2.0 * 5 * 3 * 512 * 512
+    enc_lstm_flops = B * T * 2.0 * 2 * 1024 * (512 + 256)
+    out["roofline_postnet"] = {"kernel": "convmfma::conv_mfma_kernel x 5 (implicit GEMM, v_mfma_f32_32x32x2_f32)",
+                               "bound": "mfma", "achieved": post_flops / (st["postnet"] * 1e-3) / 1e12,
+                               "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": post_flops / (st["postnet"] * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                               "algorithmic_flops": post_flops, "ms": st["postnet"]}
+    out["roofline_encoder"] = {"kernel": "3 conv blocks (MFMA conv engine) + BiLSTM (T_in dependent step launches)",
+                               "bound": "latency (T_in serial BiLSTM steps)",
+                               "achieved": (enc_conv_flops + enc_lstm_flops) / (st["encoder"] * 1e-3) / 1e12,
+                               "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": (enc_conv_flops + enc_lstm_flops) / (st["encoder"] * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                               "algorithmic_flops": enc_conv_flops + enc_lstm_flops, "ms": st["encoder"]}
 
     if rank == 0 and world == 1 and not a.no_batch1:
         ids1 = torch.as_tensor(synthetic.t2_text_ids(99, 1, 100)).to(dev)

@@ -1,8 +1,9 @@
-// Probe for the K-part GEMM of the batched decoder: out[part][4096 x 64] = W[4096 x Kpart] . X[Kpart x 64]
-// with the activation slice of a workgroup staged ONCE in LDS and every wave streaming its own weight rows
-// straight into registers.  Variants differ in the rows per workgroup.  Prints us per launch for the decoder
-// LSTM's early columns (K = 2048) and checks one tile against the host.
-//   hipcc -O3 --offload-arch=gfx950 tools/part_probe.hip -o tools/part_probe
+// Probe for the staged pieces of the batched decoder (PartOp in tts_amd/csrc/t2_decoder.hip):
+// out[part][4096 x 64] = W[4096 x 256 of part] . X[256 x 64] with the activation slice of a workgroup staged in
+// LDS and every wave streaming its own weights straight into registers.  Prints us per launch for the decoder
+// LSTM's early columns (K = 2048, 8 parts), the 100 MHz timestamps of the phases inside the first and the last
+// workgroup, and checks a few outputs against the host.
+//   hipcc -O3 --offload-arch=gfx950 tools/part_probe.hip -o tools/part_probe && tools/part_probe
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -11,73 +12,110 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int ROWS = 4096, BPAD = 64;
+constexpr int ROWS = 4096, BPAD = 64, THREADS = 512;
+constexpr int PART_K = 256, PART_KG = 16, PART_COLS = 64;
 
-// weights packed as in the decoder: [rb][kg][lane][4], lane l: row l&15, k = 4*(l>>4)+s
-// X quad-interleaved: float4 index (k/4)*BPAD + b
+__device__ long long g_marks[2][8];
+#define MARK(i)                                                                                  \
+  do {                                                                                           \
+    if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1))                    \
+      g_marks[blockIdx.x != 0][i] = wall_clock64();                                              \
+  } while (0)
 
-// NW waves per workgroup, one row block (16 rows) x 4 column tiles per wave; KP = K per part.
-template <int NW, int KP>
-__global__ __launch_bounds__(NW * 64) void part_kernel(const float* __restrict__ Wp, int kg_stride, int kg0,
-                                                       const float* __restrict__ X, float* __restrict__ out, int nparts) {
-  extern __shared__ float4 s_x[];  // [KP/4 quads][64 cols]
-  constexpr int NT = 4, KGP = KP / 16, NTHR = NW * 64;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int ngrp = ROWS / 16 / NW;
-  const int part = (blockIdx.x / ngrp) % nparts, grp = blockIdx.x % ngrp;
-  const int rb = grp * NW + wave;
-  const float4* W = reinterpret_cast<const float4*>(Wp) + ((size_t)rb * kg_stride + kg0 + part * KGP) * 64 + lane;
-  float4 wv[KGP];
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// VARIANT 0: as in the library (4 row blocks x 2 K halves per workgroup, two phases)
+// VARIANT 1: no matrix instructions (loads, staging, barriers, stores only)
+// VARIANT 2: no global loads of weights (registers hold garbage-free constants)
+template <int VARIANT>
+__global__ __launch_bounds__(THREADS) void part_kernel(const float* __restrict__ Wp, int kg_stride, const float* __restrict__ X,
+                                                       float* __restrict__ gates, int gates_part_stride, int ngrp) {
+  extern __shared__ float4 part_lds[];
+  MARK(0);
+  constexpr int NT = PART_COLS / 16, KGH = PART_KG / 2, KGP = KGH / 2;
+  constexpr int Q4 = (PART_K / 4 / 4) * PART_COLS;
+  const int wg = blockIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int part = wg / ngrp, rb = (wg % ngrp) * 4 + (wave & 3), kh = wave >> 2;
+  const float4* W = reinterpret_cast<const float4*>(Wp) + ((size_t)rb * kg_stride + part * PART_KG + kh * KGH) * 64 + lane;
+  const float4* X4 = reinterpret_cast<const float4*>(X) + (size_t)part * (PART_K / 4) * PART_COLS + threadIdx.x;
+  float4 wv[KGH], a0, a1, a2, a3, b0, b1, b2, b3;
+  a0 = X4[0], a1 = X4[THREADS], a2 = X4[2 * Q4], a3 = X4[2 * Q4 + THREADS];
 #pragma unroll
-  for (int i = 0; i < KGP; ++i) wv[i] = W[(size_t)i * 64];
-  const float4* X4 = reinterpret_cast<const float4*>(X) + (size_t)part * (KP / 4) * BPAD;
-  constexpr int NX = (KP / 4) * BPAD / NTHR;
+  for (int i = 0; i < KGP; ++i) wv[i] = VARIANT == 2 ? make_float4(1.f, 2.f, 3.f, lane) : W[(size_t)i * 64];
+  b0 = X4[Q4], b1 = X4[Q4 + THREADS], b2 = X4[3 * Q4], b3 = X4[3 * Q4 + THREADS];
 #pragma unroll
-  for (int i = 0; i < NX; ++i) s_x[threadIdx.x + NTHR * i] = X4[threadIdx.x + NTHR * i];
-  __syncthreads();
+  for (int i = KGP; i < KGH; ++i) wv[i] = VARIANT == 2 ? make_float4(1.f, 2.f, 3.f, lane) : W[(size_t)i * 64];
   f32x4 acc[NT];
 #pragma unroll
   for (int n = 0; n < NT; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const float4* xs = s_x + (lane >> 4) * BPAD + (lane & 15);
-#pragma unroll
-  for (int i = 0; i < KGP; ++i) {
-    float4 xv[NT];
-#pragma unroll
-    for (int n = 0; n < NT; ++n) xv[n] = xs[i * 4 * BPAD + n * 16];
-#define SLICE(C) _Pragma("unroll") for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[i].C, xv[n].C, acc[n], 0, 0, 0);
-    SLICE(x) SLICE(y) SLICE(z) SLICE(w)
-#undef SLICE
+  const float4* xl = part_lds + (size_t)kh * 2 * Q4 + (lane >> 4) * PART_COLS + (lane & 15);
+  float4* xw = part_lds + threadIdx.x;
+#define SLICE(C)                                                                                              \
+  _Pragma("unroll") for (int n = 0; n < NT; ++n) {                                                            \
+    if (VARIANT == 1) acc[n][0] += wv[i].C * xv[n].C;                                                         \
+    else acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[i].C, xv[n].C, acc[n], 0, 0, 0);                    \
   }
-  float4* O = reinterpret_cast<float4*>(out) + (size_t)part * (ROWS / 4) * BPAD + (size_t)(rb * 4 + (lane >> 4)) * BPAD +
+#define PHASE(PH)                                                                          \
+  lds_barrier();                                                                           \
+  MARK(1 + 2 * (PH));                                                                      \
+  _Pragma("unroll") for (int ii = 0; ii < KGP; ++ii) {                                     \
+    const int i = (PH) * KGP + ii;                                                         \
+    float4 xv[NT];                                                                         \
+    _Pragma("unroll") for (int n = 0; n < NT; ++n) xv[n] = xl[i * 4 * PART_COLS + n * 16]; \
+    SLICE(x) SLICE(y) SLICE(z) SLICE(w)                                                    \
+  }                                                                                        \
+  MARK(2 + 2 * (PH));
+  xw[0] = a0, xw[THREADS] = a1, xw[2 * Q4] = a2, xw[2 * Q4 + THREADS] = a3;
+  PHASE(0)
+  xw[Q4] = b0, xw[Q4 + THREADS] = b1, xw[3 * Q4] = b2, xw[3 * Q4 + THREADS] = b3;
+  PHASE(1)
+  lds_barrier();
+  f32x4* xc = reinterpret_cast<f32x4*>(part_lds) + (size_t)wave * 2 * 64 + lane;
+  xc[0] = kh ? acc[0] : acc[2], xc[64] = kh ? acc[1] : acc[3];
+  lds_barrier();
+  MARK(5);
+  const f32x4* pc = reinterpret_cast<const f32x4*>(part_lds) + (size_t)(wave ^ 4) * 2 * 64 + lane;
+  float4* O = reinterpret_cast<float4*>(gates) + (size_t)part * gates_part_stride + (size_t)(rb * 4 + (lane >> 4)) * PART_COLS +
               (lane & 15);
 #pragma unroll
-  for (int n = 0; n < NT; ++n) O[n * 16] = make_float4(acc[n][0], acc[n][1], acc[n][2], acc[n][3]);
+  for (int j = 0; j < 2; ++j) {
+    const f32x4 mine = kh ? acc[2 + j] : acc[j], other = pc[64 * j];
+    const f32x4 v = kh == 0 ? mine + other : other + mine;
+    O[(2 * kh + j) * 16] = make_float4(v[0], v[1], v[2], v[3]);
+  }
+  MARK(6);
 }
 
-template <int NW, int KP>
-void run(const float* dW, const float* dX, float* dO, int K, const std::vector<float>& hW, const std::vector<float>& hX) {
-  const int KG = K / 16, nparts = K / KP;
-  const size_t nO = (size_t)nparts * ROWS * BPAD, nW = (size_t)ROWS * K;
-  const int smem = (KP / 4) * BPAD * 16;
-  hipFuncSetAttribute(reinterpret_cast<const void*>(part_kernel<NW, KP>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+template <int VARIANT>
+void run(const char* what, const float* dW, const float* dX, float* dO, int K, const std::vector<float>& hW,
+         const std::vector<float>& hX, bool check) {
+  const int KG = K / 16, nparts = K / PART_K, ngrp = ROWS / 16 / 4;
+  const size_t nO = (size_t)nparts * ROWS * BPAD;
+  const int smem = PART_K * PART_COLS * 4;
+  hipFuncSetAttribute(reinterpret_cast<const void*>(part_kernel<VARIANT>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
   hipEvent_t a, b;
   hipEventCreate(&a), hipEventCreate(&b);
-  const int grid = ROWS / 16 / NW * nparts;
+  const int grid = ngrp * nparts;
   float ms = 0;
-  float t[3];
-  for (int mi = 0; mi < 3; ++mi) {
-    const int M = 1 << mi;
-    for (int rep = 0; rep < 2; ++rep) {
-      hipEventRecord(a);
-      for (int i = 0; i < 200; ++i) part_kernel<NW, KP><<<grid * M, NW * 64, smem>>>(dW, KG, 0, dX, dO, nparts);
-      hipEventRecord(b);
-      hipEventSynchronize(b);
-      hipEventElapsedTime(&ms, a, b);
-    }
-    t[mi] = ms * 5.f;
+  for (int rep = 0; rep < 2; ++rep) {
+    hipEventRecord(a);
+    for (int i = 0; i < 200; ++i)
+      part_kernel<VARIANT><<<grid, THREADS, smem>>>(dW, KG, dX, dO, ROWS / 4 * BPAD, ngrp);
+    hipEventRecord(b);
+    hipEventSynchronize(b);
+    hipEventElapsedTime(&ms, a, b);
   }
-  printf("waves %d  Kpart %3d  grid %4d  lds %3d KB  %.2f / %.2f / %.2f us per launch at 1x/2x/4x work: marginal %.2f us per 1x (%.1f TFLOP/s)",
-         NW, KP, grid, smem / 1024, t[0], t[1], t[2], (t[2] - t[0]) / 3, 2.0 * ROWS * K * BPAD / ((t[2] - t[0]) / 3 * 1e-6) / 1e12);
+  long long m[2][8];
+  hipMemcpyFromSymbol(m, HIP_SYMBOL(g_marks), sizeof(m));
+  printf("%-28s grid %4d  %.2f us per launch (%.1f TFLOP/s)\n", what, grid, ms * 5.f,
+         2.0 * ROWS * K * BPAD / (ms * 5e-6) / 1e12);
+  for (int w = 0; w < 2; ++w)
+    printf("   %s workgroup: to phase 0 %.2f us, MFMAs %.2f, to phase 1 %.2f, MFMAs %.2f, combine %.2f, store %.2f | total %.2f\n",
+           w ? "last " : "first", (m[w][1] - m[w][0]) / 100.0, (m[w][2] - m[w][1]) / 100.0, (m[w][3] - m[w][2]) / 100.0,
+           (m[w][4] - m[w][3]) / 100.0, (m[w][5] - m[w][4]) / 100.0, (m[w][6] - m[w][5]) / 100.0, (m[w][6] - m[w][0]) / 100.0);
+  printf("   last workgroup starts %.2f us after the first\n", (m[1][0] - m[0][0]) / 100.0);
+  if (!check) return;
   std::vector<float> hO(nO);
   hipMemcpy(hO.data(), dO, nO * 4, hipMemcpyDeviceToHost);
   double worst = 0;
@@ -88,7 +126,7 @@ void run(const float* dW, const float* dX, float* dO, int K, const std::vector<f
       for (int p = 0; p < nparts; ++p) got += hO[(size_t)p * ROWS * BPAD + ((size_t)(r >> 2) * BPAD + c) * 4 + (r & 3)];
       worst = fmax(worst, fabs(ref - got));
     }
-  printf("  max |err| %.3e\n", worst);
+  printf("   max |err| %.3e\n", worst);
 }
 
 int main() {
@@ -110,10 +148,8 @@ int main() {
   hipMalloc(&dW, nW * 4), hipMalloc(&dX, nX * 4), hipMalloc(&dO, nO * 4);
   hipMemcpy(dW, pW.data(), nW * 4, hipMemcpyHostToDevice);
   hipMemcpy(dX, pX.data(), nX * 4, hipMemcpyHostToDevice);
-  run<8, 256>(dW, dX, dO, K, hW, hX);
-  run<4, 256>(dW, dX, dO, K, hW, hX);
-  run<8, 128>(dW, dX, dO, K, hW, hX);
-  run<4, 128>(dW, dX, dO, K, hW, hX);
-  run<2, 128>(dW, dX, dO, K, hW, hX);
+  run<0>("as in the library", dW, dX, dO, K, hW, hX, true);
+  run<1>("no matrix instructions", dW, dX, dO, K, hW, hX, false);
+  run<2>("no weight loads", dW, dX, dO, K, hW, hX, false);
   return 0;
 }
