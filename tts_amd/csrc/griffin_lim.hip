@@ -550,11 +550,14 @@ __device__ __forceinline__ void frame_iter(const FrameP& p, int b, int i, float2
     pdft16<false>(v);
     pfft1024_pass2<false>(v, s, s_tw, lane_a, z);
     pfft1024_pass3<false>(v, s, s_tw, lane_a, z);
+    // v[4 c + r] holds bin (lane + 64 c) + 256 r.  Bins below 512 (r < 2) are this lane's own k of the pairs
+    // (k, 1024 - k) and stay in registers; only the upper half, which other lanes read as partners, goes to LDS.
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) s[lane_a + (lane_a >> 4) + 68 * c + 272 * r] = v[4 * c + r];
+      for (int r = 2; r < 4; ++r) s[lane_a + (lane_a >> 4) + 68 * c + 272 * r] = v[4 * c + r];
   }
+  const f2 Z512 = v[2];  // (lane 0: bin 512)
   GL_MARK(2);
   constexpr float SCALE = 1.0f / MC;
 #pragma unroll
@@ -566,9 +569,10 @@ __device__ __forceinline__ void frame_iter(const FrameP& p, int b, int i, float2
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
     const int k = lane_b + 64 * c;
-    Zk8[c] = s[pidx(k)], Zm8[c] = s[pidx((MC - k) & (MC - 1))];
+    Zk8[c] = v[4 * (c & 3) + (c >> 2)], Zm8[c] = s[pidx((MC - k) & (MC - 1))];
     W8[c] = s_tw2[k + z];
   }
+  Zm8[0] = lane_b == 0 ? Zk8[0] : Zm8[0];  // bin 0 is its own partner (and a lower bin: not in LDS)
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
     const int k = lane_b + 64 * c;
@@ -598,22 +602,23 @@ __device__ __forceinline__ void frame_iter(const FrameP& p, int b, int i, float2
     const f2 A = Xk2 + Ym2, Bd = Xk2 - Ym2;
     const f2 O = pk_cmul<true>(Bd, W);
     const f2 zk = pk_addpj(A, O), zm = pk_conj_addmj(A, O);
-    s[pidx(k)] = zk;
-    // (k = 0 has no partner slot: it stores its own value a second time, which keeps the store unconditional)
+    // the lower bin is input lane + 64 c of the inverse transform's first pass: it stays in this lane's registers;
+    // the upper bin travels to its lane through LDS
+    v[c] = zk;
+    // (k = 0 has no partner: it stores its own value into the unused slot 0, which keeps the store unconditional)
     s[pidx(k ? MC - k : 0)] = k ? zm : zk;
   }
   if (lane_b == 0) {
     // Bin 512 is its own partner and its twiddle is -i: X[512] = conj Z[512], Z'[512] = conj X'[512], so the new
     // value is the old one's unit phasor times the magnitude
-    const f2 Z = s[pidx(512)];
-    const float2 u = unit_phase(make_float2(Z.x, Z.y));
+    const float2 u = unit_phase(make_float2(Z512.x, Z512.y));
     s[pidx(512)] = (f2){u.x, u.y} * m512;
   }
 
   GL_MARK(3);
   // ---- synthesis: inverse transform, window, windowed frame into the wave's LDS region
 #pragma unroll
-  for (int r = 0; r < 16; ++r) v[r] = s[lane_s + (lane_s >> 4) + 68 * r];
+  for (int r = 8; r < 16; ++r) v[r] = s[lane_s + (lane_s >> 4) + 68 * r];
   pdft16<true>(v);
   pfft1024_pass2<true>(v, s, s_tw, lane_s, z);
   // the window values of the sixteen sample pairs (always inside the table) are requested before the last pass
