@@ -733,6 +733,22 @@ __global__ __launch_bounds__(64 * FR_PER_WG, 3) void gl_fused_kernel(FusedP P) {
   const float inv_hop = 1.0f / (float)q.hop;
   int cur = 0;
   const bool xmode = P.xbuf != nullptr;
+  // Interior rounds of the usual geometry (window = 4 hops, 256 <= hop <= 292) take combine_interior below: thread
+  // tid owns offset rho = tid of each of the seven hop blocks of the round's span, and the 7 (hop - 256) offsets
+  // beyond 256 are dealt one per thread (block tid / (hop - 256), offset 256 + tid % (hop - 256)).
+  constexpr int NTHR = 64 * FR_PER_WG;
+  const int n_left = q.hop - NTHR;  // offsets of a hop block beyond the first 256
+  const bool fast_geom = !xmode && q.win == FR_PER_WG * q.hop && P.carry_len == (FR_PER_WG - 1) * q.hop && n_left >= 0 &&
+                         (2 * FR_PER_WG - 1) * n_left <= NTHR;
+  float wss_left = 0.f;
+  if (fast_geom && n_left > 0) {
+    const int left_rho = NTHR + tid % n_left;
+#pragma unroll
+    for (int kk = FR_PER_WG - 1; kk >= 0; --kk) {
+      const float w = p.winpad[min(q.lpad + kk * q.hop + min(left_rho, q.hop - 1), NFFT - 1)];
+      wss_left += w * w;
+    }
+  }
   const int j_start = max(j_first - (xmode ? 0 : P.n_halo), 0);  // (nothing before the first frame)
   FrameIn fin;
   if constexpr (KIND == K_GL_ITER) {
@@ -828,8 +844,50 @@ __global__ __launch_bounds__(64 * FR_PER_WG, 3) void gl_fused_kernel(FusedP P) {
         }
       }
     };
+    // ---- the same for a round in the interior of an utterance (all four frames exist, every emitted position is
+    // fully overlapped and inside the signal): hop block h = 0 .. 6 of the span receives the carry (h < 3) and
+    // frames max(0, h - 3) .. min(3, h), frame w at in-window position (h - w) hop + rho - no range checks, no
+    // selects, the block index is a compile-time constant of each pass, and only the operands that exist are read.
+    // Same sums in the same order as combine().
+    auto combine_interior = [&](const bool emit) {
+      const int H = q.hop;
+      const float* fr[FR_PER_WG];
+#pragma unroll
+      for (int w = 0; w < FR_PER_WG; ++w) fr[w] = reinterpret_cast<const float*>(s_data[w]) + shift;
+      float* outp = PADDED ? P.out + (size_t)b * q.LP + q.lpad + (size_t)FR_PER_WG * j * H
+                           : P.out + (size_t)b * Lmax + ((size_t)FR_PER_WG * j * H + q.lpad - NFFT / 2);
+      auto block_sum = [&](const int h, const int rho) {
+        float acc = h < FR_PER_WG - 1 ? c_old[h * H + rho] : 0.f;
+#pragma unroll
+        for (int w = 0; w < FR_PER_WG; ++w)
+          if (w <= h && h - w < FR_PER_WG) acc += fr[w][(h - w) * H + rho];
+        return acc;
+      };
+#pragma unroll
+      for (int h = 0; h < 2 * FR_PER_WG - 1; ++h) {
+        if (!(emit || h >= FR_PER_WG)) continue;
+        const float v = block_sum(h, tid);
+        if (h >= FR_PER_WG) c_new[(h - FR_PER_WG) * H + tid] = v;
+        else outp[h * H + tid] = wss_full[0] > 1.17549435e-38f ? v / wss_full[0] : v;
+      }
+      // the offsets beyond 256: one (block, offset) per thread
+      const int left_h = n_left > 0 ? tid / n_left : 0, left_rho = NTHR + (n_left > 0 ? tid % n_left : 0);
+      if (tid < (2 * FR_PER_WG - 1) * n_left && (emit || left_h >= FR_PER_WG)) {
+        const int h = left_h, rho = left_rho;
+        float acc = h < FR_PER_WG - 1 ? c_old[h * H + rho] : 0.f;
+#pragma unroll
+        for (int w = 0; w < FR_PER_WG; ++w) {
+          const int d = h - w;
+          const float f = fr[w][min(max(d, 0), FR_PER_WG - 1) * H + rho];
+          acc += (d >= 0 && d < FR_PER_WG) ? f : 0.f;
+        }
+        if (h >= FR_PER_WG) c_new[(h - FR_PER_WG) * H + rho] = acc;
+        else outp[h * H + rho] = wss_left > 1.17549435e-38f ? acc / wss_left : acc;
+      }
+    };
     if (!xmode) {
-      combine(j >= j_first, true);
+      if (fast_geom && FR_PER_WG * j + FR_PER_WG - 1 < Fb && (j >= 1 || j < j_first)) combine_interior(j >= j_first);
+      else combine(j >= j_first, true);
       cur ^= 1;
       GL_MARK_NV(7);
       continue;
