@@ -194,6 +194,39 @@ def test_stft_geometries_at_the_limits(hop, win, v1):
     assert _snr_db(g_ref, g) >= 40.0
 
 
+@pytest.mark.parametrize("hop,win", [(275, 1100), (256, 1024), (270, 1080), (274, 1096)])
+def test_griffin_lim_long_runs_equal_one_utterance_runs(hop, win):
+    """A ragged batch whose workgroups own several rounds of four frames each (the overlap-add of a round in the
+    interior of an utterance takes the pass-per-hop-block form where the window is four hops of 256..292 samples;
+    (274, 1096) is four hops too, but with an even left padding of the window the other three do not have)
+    against the same utterances run one at a time (one round per workgroup, carry from the neighbour, general
+    overlap-add): the same bits; and against the oracle."""
+    from oracle import audio_oracle as ao
+    from tts_amd import synthetic
+    from tts_amd.audio import AudioProcessor
+    cfg = dict(ao.T2_AUDIO, sample_rate=1000, frame_shift_ms=float(hop), frame_length_ms=float(win), mel_fmin=0.0,
+               mel_fmax=None, griffin_lim_iters=3)
+    orc = ao.AudioOracle(**cfg)
+    ap = AudioProcessor(verbose=False, **{k: v for k, v in cfg.items() if k not in ("pad_mode", "win_from_hop")})
+    assert (ap.hop_length, ap.win_length) == (hop, win)
+    Fs = [700, 699, 698, 697, 333, 9]
+    B, Fm = len(Fs), max(Fs)
+    gen = torch.Generator().manual_seed(hop)
+    mag = torch.rand(B, Fm, 1025, generator=gen) + 0.05
+    ph = torch.rand(B, Fm, 1025, generator=gen)
+    wav = ap.griffin_lim_batch(mag.cuda(), ph.cuda(), torch.tensor(Fs), deemphasis=False).cpu().numpy()
+    for b, F in enumerate(Fs):
+        L = hop * (F - 1)
+        one = ap.griffin_lim_batch(mag[b:b + 1, :F].contiguous().cuda(), ph[b:b + 1, :F].contiguous().cuda(),
+                                   torch.tensor([F]), deemphasis=False).cpu().numpy()
+        assert np.array_equal(one[0, :L], wav[b, :L]), b
+        assert np.abs(wav[b, L:]).max(initial=0.0) == 0.0
+    for b in (1, 5):
+        F = Fs[b]
+        ref = orc._griffin_lim(mag[b, :F].numpy().T.copy(), ph[b, :F].numpy().T.astype(np.float64).copy())
+        assert _snr_db(ref, wav[b, :hop * (F - 1)]) >= 40.0, b
+
+
 def test_device_de_emphasis_equals_lfilter():
     """The blocked-scan de-emphasis kernel against scipy.signal.lfilter (fp64) applied to the same raw Griffin-Lim
     output, over several workgroup chunks (16 384 samples each) and on a ragged batch; and the coefficient range
