@@ -739,6 +739,17 @@ __global__ __launch_bounds__(GEMM_THREADS) void triple_kernel(typename A::P pa, 
   else B::run(pb, wg - na - nc);
 }
 
+// The same with op B's workgroups dispatched before op C's (C: workgroups that start by waiting for op A's - they
+// should not hold slots that B's could work in).
+template <class A, class C, class B>
+__global__ __launch_bounds__(GEMM_THREADS) void triple_kernel_b_first(typename A::P pa, typename C::P pc, typename B::P pb,
+                                                                      int na, int nb) {
+  const int wg = blockIdx.x;
+  if (wg < na) A::run(pa, wg);
+  else if (wg < na + nb) B::run(pb, wg - na);
+  else C::run(pc, wg - na - nb);
+}
+
 // ------------------------------------------------------------------ attention
 struct AttnP {
   const float* q;        // quad [128]
@@ -2208,8 +2219,8 @@ int enqueue_step(ttsx_t2_decoder* d, int i, bool first, bool more, hipStream_t s
       triple_kernel<ProjOp, Prenet2AfterProjOp, NoOp><<<na + nc, GEMM_THREADS, 0, st>>>(g, g2, 0, na, nc);
     } else if (nt % 2 == 0 && pc.g.nrb % 2 == 0) {
       const int nb = pc.g.nrb / 2 * (nt / 2) * pc.nk;
-      triple_kernel<ProjOp, Prenet2AfterProjOp, GemmOp<2, 2, PK1 / 2, MODE_PARTIAL>>
-          <<<na + nc + nb, GEMM_THREADS, 0, st>>>(g, g2, pc.g, na, nc);
+      triple_kernel_b_first<ProjOp, Prenet2AfterProjOp, GemmOp<2, 2, PK1 / 2, MODE_PARTIAL>>
+          <<<na + nb + nc, GEMM_THREADS, 0, st>>>(g, g2, pc.g, na, nb);
     } else {
       const int nb = pc.g.nrb * nt * pc.nk;
       triple_kernel<ProjOp, Prenet2AfterProjOp, GemmOp<1, 1, PK1 / 2, MODE_PARTIAL>>
