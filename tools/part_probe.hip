@@ -27,6 +27,7 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // VARIANT 0: as in the library (4 row blocks x 2 K halves per workgroup, two phases)
 // VARIANT 1: no matrix instructions (loads, staging, barriers, stores only)
 // VARIANT 2: no global loads of weights (registers hold garbage-free constants)
+// VARIANT 3: the whole slice first, the weights requested once it has arrived, one phase
 template <int VARIANT>
 __global__ __launch_bounds__(THREADS) void part_kernel(const float* __restrict__ Wp, int kg_stride, const float* __restrict__ X,
                                                        float* __restrict__ gates, int gates_part_stride, int ngrp) {
@@ -40,6 +41,53 @@ __global__ __launch_bounds__(THREADS) void part_kernel(const float* __restrict__
   const float4* W = reinterpret_cast<const float4*>(Wp) + ((size_t)rb * kg_stride + part * PART_KG + kh * KGH) * 64 + lane;
   const float4* X4 = reinterpret_cast<const float4*>(X) + (size_t)part * (PART_K / 4) * PART_COLS + threadIdx.x;
   float4 wv[KGH], a0, a1, a2, a3, b0, b1, b2, b3;
+  if (VARIANT == 3) {
+    // the whole slice first, then the weights: the L2 hits of the slice do not queue behind the weight misses
+    a0 = X4[0], a1 = X4[THREADS], a2 = X4[2 * Q4], a3 = X4[2 * Q4 + THREADS];
+    b0 = X4[Q4], b1 = X4[Q4 + THREADS], b2 = X4[3 * Q4], b3 = X4[3 * Q4 + THREADS];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the weights are requested once the slice has arrived)
+    float4* xw0 = part_lds + threadIdx.x;
+    xw0[0] = a0, xw0[THREADS] = a1, xw0[2 * Q4] = a2, xw0[2 * Q4 + THREADS] = a3;
+    xw0[Q4] = b0, xw0[Q4 + THREADS] = b1, xw0[3 * Q4] = b2, xw0[3 * Q4 + THREADS] = b3;
+#pragma unroll
+    for (int i = 0; i < KGH; ++i) wv[i] = W[(size_t)i * 64];
+    lds_barrier();
+    MARK(1);
+    f32x4 acc3[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc3[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float4* xl3 = part_lds + (size_t)kh * 2 * Q4 + (lane >> 4) * PART_COLS + (lane & 15);
+#pragma unroll
+    for (int i = 0; i < KGH; ++i) {
+      float4 xv[4];
+#pragma unroll
+      for (int n = 0; n < 4; ++n) xv[n] = xl3[i * 4 * PART_COLS + n * 16];
+#define SL3(C) _Pragma("unroll") for (int n = 0; n < 4; ++n) acc3[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[i].C, xv[n].C, acc3[n], 0, 0, 0);
+      SL3(x) SL3(y) SL3(z) SL3(w)
+#undef SL3
+      if (i == KGH / 2 - 1) {
+        MARK(2);
+        MARK(3);
+      }
+    }
+    MARK(4);
+    lds_barrier();
+    f32x4* xc3 = reinterpret_cast<f32x4*>(part_lds) + (size_t)wave * 2 * 64 + lane;
+    xc3[0] = kh ? acc3[0] : acc3[2], xc3[64] = kh ? acc3[1] : acc3[3];
+    lds_barrier();
+    MARK(5);
+    const f32x4* pc3 = reinterpret_cast<const f32x4*>(part_lds) + (size_t)(wave ^ 4) * 2 * 64 + lane;
+    float4* O3 = reinterpret_cast<float4*>(gates) + (size_t)part * gates_part_stride + (size_t)(rb * 4 + (lane >> 4)) * PART_COLS +
+                 (lane & 15);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const f32x4 mine = kh ? acc3[2 + j] : acc3[j], other = pc3[64 * j];
+      const f32x4 v = kh == 0 ? mine + other : other + mine;
+      O3[(2 * kh + j) * 16] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    MARK(6);
+    return;
+  }
   a0 = X4[0], a1 = X4[THREADS], a2 = X4[2 * Q4], a3 = X4[2 * Q4 + THREADS];
 #pragma unroll
   for (int i = 0; i < KGP; ++i) wv[i] = VARIANT == 2 ? make_float4(1.f, 2.f, 3.f, lane) : W[(size_t)i * 64];
@@ -151,5 +199,6 @@ int main() {
   run<0>("as in the library", dW, dX, dO, K, hW, hX, true);
   run<1>("no matrix instructions", dW, dX, dO, K, hW, hX, false);
   run<2>("no weight loads", dW, dX, dO, K, hW, hX, false);
+  run<3>("slice first, then weights", dW, dX, dO, K, hW, hX, true);
   return 0;
 }
