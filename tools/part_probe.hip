@@ -1,8 +1,11 @@
-// Probe for the staged pieces of the batched decoder (PartOp in tts_amd/csrc/t2_decoder.hip):
+// Probe of a piece kernel for the batched decoder that was measured and NOT adopted (the library's pieces are the
+// register-prefetch tiles of GemmOp in tts_amd/csrc/t2_decoder.hip):
 // out[part][4096 x 64] = W[4096 x 256 of part] . X[256 x 64] with the activation slice of a workgroup staged in
 // LDS and every wave streaming its own weights straight into registers.  Prints us per launch for the decoder
 // LSTM's early columns (K = 2048, 8 parts), the 100 MHz timestamps of the phases inside the first and the last
-// workgroup, and checks a few outputs against the host.
+// workgroup, and checks a few outputs against the host.  What it shows: a workgroup spends 3-6 us before its first
+// matrix instruction (the L2 hits of the slice queue behind weight misses issued earlier on the same CU), then the
+// matrix pipe of the CU is the bound - and all workgroups of a launch do both at the same time.
 //   hipcc -O3 --offload-arch=gfx950 tools/part_probe.hip -o tools/part_probe && tools/part_probe
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -24,7 +27,7 @@ __device__ long long g_marks[2][8];
 
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// VARIANT 0: as in the library (4 row blocks x 2 K halves per workgroup, two phases)
+// VARIANT 0: 4 row blocks x 2 K halves per workgroup, the slice in two phases
 // VARIANT 1: no matrix instructions (loads, staging, barriers, stores only)
 // VARIANT 2: no global loads of weights (registers hold garbage-free constants)
 // VARIANT 3: the whole slice first, the weights requested once it has arrived, one phase
@@ -196,7 +199,7 @@ int main() {
   hipMalloc(&dW, nW * 4), hipMalloc(&dX, nX * 4), hipMalloc(&dO, nO * 4);
   hipMemcpy(dW, pW.data(), nW * 4, hipMemcpyHostToDevice);
   hipMemcpy(dX, pX.data(), nX * 4, hipMemcpyHostToDevice);
-  run<0>("as in the library", dW, dX, dO, K, hW, hX, true);
+  run<0>("slice in two phases", dW, dX, dO, K, hW, hX, true);
   run<1>("no matrix instructions", dW, dX, dO, K, hW, hX, false);
   run<2>("no weight loads", dW, dX, dO, K, hW, hX, false);
   run<3>("slice first, then weights", dW, dX, dO, K, hW, hX, true);
