@@ -504,6 +504,9 @@ def main():
                          "stage_ms": s1, "decoder_us_per_step": d_us,
                          "decoder_hbm_gbs": dec_step_bytes(1, 100) / (d_us * 1e-6) / 1e9,
                          "decoder_hbm_frac": dec_step_bytes(1, 100) / (d_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                         # the same against what a plain streaming read of an Infinity-Cache-resident 76 MB buffer
+                         # reaches on this part (tools/stream_probe.hip: 6.6 TB/s; from HBM 6.1 TB/s)
+                         "decoder_vs_measured_stream_frac": dec_step_bytes(1, 100) / (d_us * 1e-6) / 1e9 / 6600.0,
                          "workload": "B=1, T_in=100, %d decoder steps, r=%d" % (S, r),
                          "decoder_path": "persistent team kernel: one launch per run, LSTM weights resident in "
                                          "registers and LDS (decoder_hbm_* price the step at the launch chain's "
