@@ -27,6 +27,7 @@ The JSON line also carries
                 from HIP-event timing on the launch stream inside this run;
   roofline_gl   the Griffin-Lim stage against the HBM and vector-ALU peaks;
   roofline_postnet / roofline_encoder   the conv stacks (and the encoder BiLSTM) against the fp32-MFMA peak;
+  decoder_by_batch  the decoder step at batch 128 and 256 (the corpus workload's batch) against the same peak;
   cpu_baseline  the CPU oracle (a restatement of the reference's PyTorch/NumPy path) timed on
                 this box's host cores on a bounded sample of the same workload (rank 0, N=1);
   batch1        batch-1 latency and real-time factor of the same path, fixed 800 steps;
@@ -293,7 +294,7 @@ def launch_ranks(a, argv):
 def corpus_plan_summary(a, world):
     from tts_amd import corpus
     lengths = corpus.corpus_lengths(a.corpus_utts, seed=1234)
-    batches = corpus.plan_batches(lengths, a.batch)
+    batches = corpus.plan_batches(lengths, a.corpus_batch)
     return lengths, batches, corpus.deal(batches, lengths, world, "lpt")
 
 
@@ -331,7 +332,7 @@ def run_corpus(a, model, ap, rank, world, dist, dev, n_utts, shard_of=None):
     lengths = corpus.corpus_lengths(n_utts, seed=1234)
     texts = corpus.corpus_texts(lengths, seed=1234)
     w, r_ = (world, rank) if shard_of is None else shard_of
-    staged = corpus.StagedCorpus(model, ap, lengths, texts, batch=a.batch, world=w, rank=r_, policy="lpt",
+    staged = corpus.StagedCorpus(model, ap, lengths, texts, batch=a.corpus_batch, world=w, rank=r_, policy="lpt",
                                  steps_per_id=6, max_steps=3000, device=dev)
     dt, busy = corpus.timed_steps(staged.run, a.steps, a.warmup, dist, dev, own=True)
     stats = corpus.gather_rank_stats([staged.frames, staged.frames_padded, busy / a.steps, staged.n_utts,
@@ -340,7 +341,7 @@ def run_corpus(a, model, ap, rank, world, dist, dev, n_utts, shard_of=None):
     ms = dt / a.steps * 1e3
     return {"workload": "Tacotron2, %d-utterance synthetic corpus (T_in uniform 20..200, seed 1234), min(3000, 6 x T_in) "
                         "decoder steps, r=%d, length-sorted batches of %d dealt longest-processing-time first%s, "
-                        "postnet + 60-iter Griffin-Lim" % (n_utts, staged.r, a.batch,
+                        "postnet + 60-iter Griffin-Lim" % (n_utts, staged.r, a.corpus_batch,
                                                             "" if shard_of is None else
                                                             "; share %d of %d" % (shard_of[1], shard_of[0])),
             "frames": frames, "ms_per_pass": ms, "frames_per_s": frames / (ms * 1e-3),
@@ -360,6 +361,10 @@ def main():
     p.add_argument("--dec-steps", type=int, default=800)
     p.add_argument("--r", type=int, default=1)
     p.add_argument("--corpus-utts", type=int, default=4096)
+    # utterances per length-sorted batch of the corpus workload (measured on one GPU, whole corpus: 64 -> 840 k
+    # frames/s, 128 -> 999 k, 256 -> 1.12 M: weights and launch latencies are shared by more columns; the
+    # longest-processing-time-first deal of the 16 batches over 8 ranks stays within 0.5 % of balance)
+    p.add_argument("--corpus-batch", type=int, default=256)
     p.add_argument("--cpu-sample-steps", type=int, default=1600)  # ~11 s of host work
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-batch1", action="store_true")
@@ -538,6 +543,28 @@ def main():
         out["longform"] = {"workload": "B=1, T_in=1000, 2000 decoder steps, r=%d" % r, "latency_s": latL,
                            "real_time_factor": latL / (2000 * r * 275 / 22050.0), "stage_ms": sL,
                            "decoder_us_per_step": sL["decoder"] * 1e3 / 2000}
+        # the same decoder at the batch sizes the corpus workload runs: marginal time per step between a 200-step and
+        # a 100-step run (set-up cancels), against the fp32-MFMA peak.  The step of the headline batch (64 columns) is
+        # bound by its chain of dependent launches; wider batches amortise it.
+        sweep = []
+        for Bs in (128, 256):
+            ids_s = torch.as_tensor(synthetic.t2_text_ids(500 + Bs, Bs, T)).to(dev)
+            enc_s = model.encode(ids_s)
+
+            def dec_time(steps, reps=2):
+                model.decode(enc_s, None, fixed_steps=steps)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    model.decode(enc_s, None, fixed_steps=steps)
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t0) / reps
+            us = (dec_time(200) - dec_time(100)) / 100 * 1e6
+            tf = dec_step_flops(Bs, T) / (us * 1e-6) / 1e12
+            sweep.append({"batch": Bs, "T_in": T, "us_per_step": us, "achieved": tf, "unit": "TFLOP/s",
+                          "frac": tf / MFMA_F32_PEAK_TFLOPS})
+            del ids_s, enc_s
+        out["decoder_by_batch"] = sweep
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(sd, T, a.cpu_sample_steps, r)
         # the same path on one host thread (a quarter of the sample), as a scalar reference point

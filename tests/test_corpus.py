@@ -110,13 +110,13 @@ def test_bench_launcher_starts_n_ranks_with_distinct_shards():
     assert line["dry_run"] and line["n_gpus"] == 2 and len(line["ranks"]) == 2
     r0, r1 = line["ranks"]
     assert (r0["rank"], r1["rank"]) == (0, 1)
-    assert r0["utterances"] + r1["utterances"] == 4096 and r0["batches"] + r1["batches"] == 64
+    assert r0["utterances"] + r1["utterances"] == 4096 and r0["batches"] + r1["batches"] == 16   # batches of 256
     assert r0["utt_checksum"] != r1["utt_checksum"]
     lengths = corpus.corpus_lengths(4096, seed=1234)
     assert line["total_frames"] == float(np.minimum(3000, 6 * lengths).sum())
     assert abs(r0["frames"] - r1["frames"]) < 0.02 * line["total_frames"]        # LPT balance
     # the same plan, derived here
-    batches = corpus.plan_batches(lengths, 64)
+    batches = corpus.plan_batches(lengths, 256)
     dealt = corpus.deal(batches, lengths, 2, "lpt")
     for r, info in enumerate((r0, r1)):
         utts = sorted(int(i) for b in dealt[r] for i in batches[b])
