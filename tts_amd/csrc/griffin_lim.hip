@@ -479,8 +479,9 @@ __device__ __forceinline__ void pfft1024_pass3(f2 (&v)[16], f2* s, const f2* s_t
 // Factors of two are not applied where they fall: the analysis side works on 2 X (only its phase is used), the
 // synthesis side on 2 Z, and the target magnitudes carry 1/2 and the 1/1024 of the inverse transform (powers of two:
 // the same bits as scaling at the end).
-// The frame's input, requested one round ahead (frame_prefetch) so that the memory round trip (~2 us under load)
-// passes behind the overlap-add of the round before: x[r] = samples 2m, 2m+1 at m = lane + 64 r.
+// The frame's input: x[r] = samples 2m, 2m+1 at m = lane + 64 r, requested at the start of the frame.  (Requested one
+// round ahead, across the overlap-add, the 32 registers it holds there cost more in spilled registers than the
+// memory round trip it hides: the other workgroups of the CU fill that gap.)
 struct FrameIn {
   f2 x[16];
 };
@@ -690,6 +691,13 @@ struct FusedP {
   // neighbour from there.  Null: halo rounds.
   unsigned long long* xbuf;
   unsigned xtag;            // this launch's tag (never repeats on a handle)
+  // Several rounds per workgroup without the halo round (`stash` non-null; the window is four hops of 256 .. 292
+  // samples): every workgroup publishes the carry of its LAST round in xbuf.  A workgroup whose first round lies in
+  // the interior of the utterance starts without a carry: the three hop blocks of that round that need one are
+  // not emitted but their frame terms are kept in `stash` ([b][x][6][hop]: block 0 has one term, block 1 two,
+  // block 2 three), and when its run is done it takes the left neighbour's carry and adds carry and terms in the
+  // usual order - the same bits as with a halo round, one round of frames less per run.
+  float* stash;
 };
 
 template <int KIND, int PADDED>
@@ -732,7 +740,8 @@ __global__ __launch_bounds__(64 * FR_PER_WG, 3) void gl_fused_kernel(FusedP P) {
   }
   const float inv_hop = 1.0f / (float)q.hop;
   int cur = 0;
-  const bool xmode = P.xbuf != nullptr;
+  const bool dmode = KIND == K_GL_ITER && P.stash != nullptr;
+  const bool xmode = P.xbuf != nullptr && !dmode;
   // Interior rounds of the usual geometry (window = 4 hops, 256 <= hop <= 292) take combine_interior below: thread
   // tid owns offset rho = tid of each of the seven hop blocks of the round's span, and the 7 (hop - 256) offsets
   // beyond 256 are dealt one per thread (block tid / (hop - 256), offset 256 + tid % (hop - 256)).
@@ -749,11 +758,11 @@ __global__ __launch_bounds__(64 * FR_PER_WG, 3) void gl_fused_kernel(FusedP P) {
       wss_left += w * w;
     }
   }
-  const int j_start = max(j_first - (xmode ? 0 : P.n_halo), 0);  // (nothing before the first frame)
-  FrameIn fin;
-  if constexpr (KIND == K_GL_ITER) {
-    if (j_start < j_end && FR_PER_WG * j_start + wave < Fb) frame_prefetch(p, b, FR_PER_WG * j_start + wave, lane, fin);
-  }
+  // (dmode) this workgroup starts without a carry and takes its left neighbour's when its run is done
+  const bool defer_me = dmode && fast_geom && blockIdx.x > 0 && j_first >= 1 && j_first < j_end &&
+                        FR_PER_WG * j_first + FR_PER_WG - 1 < Fb;
+  float* stash = defer_me ? P.stash + ((size_t)b * gridDim.x + blockIdx.x) * 6 * q.hop : nullptr;
+  const int j_start = max(j_first - ((xmode || defer_me) ? 0 : P.n_halo), 0);  // (nothing before the first frame)
   for (int j = j_start; j < j_end; ++j) {
     __syncthreads();      // tables / carry ready; the previous round's combine has read the frames
     const int i = FR_PER_WG * j + wave;
@@ -763,13 +772,12 @@ __global__ __launch_bounds__(64 * FR_PER_WG, 3) void gl_fused_kernel(FusedP P) {
     constexpr bool mark = false;
 #endif
     if (i < Fb) {
-      if constexpr (KIND == K_GL_ITER) frame_iter(p, b, i, s_data[wave], s_tw, s_tw2, lane, fin, mark);
+      if constexpr (KIND == K_GL_ITER) {
+        FrameIn fin;
+        frame_prefetch(p, b, i, lane, fin);
+        frame_iter(p, b, i, s_data[wave], s_tw, s_tw2, lane, fin, mark);
+      }
       else frame_body<KIND, true>(p, b, i, s_data[wave], s_tw, s_tw2, lane);
-    }
-    if constexpr (KIND == K_GL_ITER) {
-      // the next round's input: in flight across the overlap-add below
-      __builtin_amdgcn_sched_barrier(0);  // (not hoisted into the frame code, where registers are scarce)
-      if (j + 1 < j_end && i + FR_PER_WG < Fb) frame_prefetch(p, b, i + FR_PER_WG, lane, fin);
     }
     __syncthreads();
     GL_MARK_NV(6);
@@ -849,7 +857,9 @@ __global__ __launch_bounds__(64 * FR_PER_WG, 3) void gl_fused_kernel(FusedP P) {
     // frames max(0, h - 3) .. min(3, h), frame w at in-window position (h - w) hop + rho - no range checks, no
     // selects, the block index is a compile-time constant of each pass, and only the operands that exist are read.
     // Same sums in the same order as combine().
-    auto combine_interior = [&](const bool emit) {
+    // keep: the round is the first of a run that started without a carry - the blocks that need one (h < 3) are
+    // not emitted, their frame terms go to the stash (term w of block h in slot h (h + 1) / 2 + w)
+    auto combine_interior = [&](const bool emit, const bool keep) {
       const int H = q.hop;
       const float* fr[FR_PER_WG];
 #pragma unroll
@@ -866,13 +876,22 @@ __global__ __launch_bounds__(64 * FR_PER_WG, 3) void gl_fused_kernel(FusedP P) {
 #pragma unroll
       for (int h = 0; h < 2 * FR_PER_WG - 1; ++h) {
         if (!(emit || h >= FR_PER_WG)) continue;
+        if (keep && h < FR_PER_WG - 1) {
+#pragma unroll
+          for (int w = 0; w <= h; ++w) stash[(h * (h + 1) / 2 + w) * H + tid] = fr[w][(h - w) * H + tid];
+          continue;
+        }
         const float v = block_sum(h, tid);
         if (h >= FR_PER_WG) c_new[(h - FR_PER_WG) * H + tid] = v;
         else outp[h * H + tid] = wss_full[0] > 1.17549435e-38f ? v / wss_full[0] : v;
       }
       // the offsets beyond 256: one (block, offset) per thread
       const int left_h = n_left > 0 ? tid / n_left : 0, left_rho = NTHR + (n_left > 0 ? tid % n_left : 0);
-      if (tid < (2 * FR_PER_WG - 1) * n_left && (emit || left_h >= FR_PER_WG)) {
+      if (keep && tid < (FR_PER_WG - 1) * n_left) {
+#pragma unroll
+        for (int w = 0; w < FR_PER_WG - 1; ++w)
+          if (w <= left_h) stash[(left_h * (left_h + 1) / 2 + w) * H + left_rho] = fr[w][(left_h - w) * H + left_rho];
+      } else if (tid < (2 * FR_PER_WG - 1) * n_left && (emit || left_h >= FR_PER_WG)) {
         const int h = left_h, rho = left_rho;
         float acc = h < FR_PER_WG - 1 ? c_old[h * H + rho] : 0.f;
 #pragma unroll
@@ -886,7 +905,8 @@ __global__ __launch_bounds__(64 * FR_PER_WG, 3) void gl_fused_kernel(FusedP P) {
       }
     };
     if (!xmode) {
-      if (fast_geom && FR_PER_WG * j + FR_PER_WG - 1 < Fb && (j >= 1 || j < j_first)) combine_interior(j >= j_first);
+      if (fast_geom && FR_PER_WG * j + FR_PER_WG - 1 < Fb && (j >= 1 || j < j_first))
+        combine_interior(j >= j_first, defer_me && j == j_first);
       else combine(j >= j_first, true);
       cur ^= 1;
       GL_MARK_NV(7);
@@ -928,6 +948,59 @@ __global__ __launch_bounds__(64 * FR_PER_WG, 3) void gl_fused_kernel(FusedP P) {
     }
     __syncthreads();
     combine(true, false);
+  }
+  if (dmode) {
+    typedef unsigned long long u64;
+    constexpr int NT = 64 * FR_PER_WG;
+    const int H = q.hop;
+    // the carry of the last round, for the right neighbour
+    __syncthreads();
+    const float* c_fin = s_carry + cur * P.carry_len;
+    u64* mine = P.xbuf + ((size_t)b * gridDim.x + blockIdx.x) * P.carry_len;
+    for (int k = tid; k < P.carry_len; k += NT)
+      __hip_atomic_store(mine + k, ((u64)P.xtag << 32) | __float_as_uint(c_fin[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (defer_me) {
+      // the left neighbour's (it has the lower block index and publishes before it waits; bounded all the same)
+      float* c_in = s_carry + (cur ^ 1) * P.carry_len;
+      const u64* left = mine - P.carry_len;
+      constexpr int XU = (WP + NT - 1) / NT;  // carry_len < win <= WP
+      for (long spin = 0;; ++spin) {
+        u64 v[XU];
+        bool ok = true;
+#pragma unroll
+        for (int m = 0; m < XU; ++m) {
+          const int k = tid + NT * m;
+          v[m] = __hip_atomic_load(left + min(k, P.carry_len - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok = ok && (k >= P.carry_len || (unsigned)(v[m] >> 32) == P.xtag);
+        }
+        if (__all(ok) || spin > 40000000) {
+#pragma unroll
+          for (int m = 0; m < XU; ++m)
+            if (tid + NT * m < P.carry_len) c_in[tid + NT * m] = ok ? __uint_as_float((unsigned)v[m]) : __builtin_nanf("");
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      __syncthreads();
+      // the three blocks of the first round that were kept back: carry, then the frame terms in frame order
+      float* outp = PADDED ? P.out + (size_t)b * q.LP + q.lpad + (size_t)FR_PER_WG * j_first * H
+                           : P.out + (size_t)b * Lmax + ((size_t)FR_PER_WG * j_first * H + q.lpad - NFFT / 2);
+#pragma unroll
+      for (int h = 0; h < FR_PER_WG - 1; ++h) {
+        float acc = c_in[h * H + tid];
+#pragma unroll
+        for (int w = 0; w <= h; ++w) acc += stash[(h * (h + 1) / 2 + w) * H + tid];
+        outp[h * H + tid] = wss_full[0] > 1.17549435e-38f ? acc / wss_full[0] : acc;
+      }
+      if (tid < (FR_PER_WG - 1) * n_left) {
+        const int h = tid / n_left, rho = NTHR + tid % n_left;
+        float acc = c_in[h * H + rho];
+#pragma unroll
+        for (int w = 0; w < FR_PER_WG - 1; ++w)
+          if (w <= h) acc += stash[(h * (h + 1) / 2 + w) * H + rho];
+        outp[h * H + rho] = wss_left > 1.17549435e-38f ? acc / wss_left : acc;
+      }
+    }
   }
   if (PADDED) {
     // the first lpad samples and the tail beyond the last round belong to nobody's slot
@@ -1220,7 +1293,9 @@ int check_gl_args(const float* mag, const float* init_phase, const float* wav, i
 struct GlPlan {
   int n_rounds, n_halo, carry_len, C;
   bool exchange;      // one round per workgroup and the carry fits the neighbour scheme (see FusedP::xbuf)
+  bool defer;         // several rounds per workgroup, no halo round (see FusedP::stash)
   size_t xbuf_words;  // carry words of such a launch
+  size_t stash_floats;
 };
 GlPlan gl_plan(const ttsx_stft_params* sp, int B, int F) {
   const FrameGeom q = make_geom(sp, F);
@@ -1237,6 +1312,13 @@ GlPlan gl_plan(const ttsx_stft_params* sp, int B, int F) {
   pl.C = std::max(1, ceil_div(pl.n_rounds, std::max(1, CUS * WGS_PER_CU / B)));
   pl.exchange = pl.C == 1 && pl.n_halo >= 1 && pl.carry_len >= 1 && pl.carry_len <= FR_PER_WG * q.hop;
   pl.xbuf_words = (size_t)B * pl.n_rounds * pl.carry_len;
+  pl.defer = pl.C > 1 && pl.n_halo == 1 && q.win == FR_PER_WG * q.hop && q.hop >= 64 * FR_PER_WG &&
+             (2 * FR_PER_WG - 1) * (q.hop - 64 * FR_PER_WG) <= 64 * FR_PER_WG;
+  if (pl.defer) {
+    const size_t runs = (size_t)B * ceil_div(pl.n_rounds, pl.C);
+    pl.xbuf_words = runs * pl.carry_len;
+    pl.stash_floats = round_up((int)(runs * 6 * q.hop), 2);
+  }
   return pl;
 }
 
@@ -1253,6 +1335,7 @@ int enqueue_griffin_lim(const float2* tw, const float* winpad, float* const ybuf
   const GlPlan pl = gl_plan(sp, B, F);
   P.n_rounds = pl.n_rounds, P.n_halo = pl.n_halo, P.carry_len = pl.carry_len, P.C = pl.C;
   const bool exchange = pl.exchange && xbuf && xtag;
+  const bool defer = pl.defer && xbuf && xtag;  // (the iteration launches; the initial synthesis keeps its halo round)
   if (exchange) P.xbuf = xbuf;
   const dim3 grid(ceil_div(P.n_rounds, P.C), B), refl_grid(NFFT / 256, B);
   const size_t smem = 2 * (size_t)std::max(P.carry_len, 1) * sizeof(float);
@@ -1267,7 +1350,8 @@ int enqueue_griffin_lim(const float2* tw, const float* winpad, float* const ybuf
   for (int it = 0; it < iters; ++it) {
     if (reflect) reflect_pad_kernel<<<refl_grid, 256, 0, st>>>(ybuf[cur], n_frames, B, F, q);
     P.f.ypad = ybuf[cur];
-    if (exchange) P.xtag = ++*xtag;
+    if (defer) P.xbuf = xbuf, P.stash = reinterpret_cast<float*>(xbuf + pl.xbuf_words);
+    if (exchange || defer) P.xtag = ++*xtag;
     const bool last = it + 1 == iters;
     if (last && direct) {
       P.out = wav;
@@ -1397,23 +1481,24 @@ extern "C" int ttsx_vocoder_griffin_lim(ttsx_vocoder* v, const float* mag, const
   if ((rc = grow(&v->ypad, &v->cap_ypad, 2 * n_pad, st))) return rc;
   float* const ybuf[2] = {v->ypad, v->ypad + n_pad};
   const GlPlan pl = gl_plan(&v->sp, B, F);
-  if (pl.exchange) {
+  if (pl.exchange || pl.defer) {
     const bool wrap = v->xtag > 0xfffffff0u - (unsigned)(iters + 1);
-    if (pl.xbuf_words > v->cap_xbuf || wrap) {
+    const size_t words = pl.xbuf_words + pl.stash_floats / 2;  // (the stash of the no-halo scheme behind the carries)
+    if (words > v->cap_xbuf || wrap) {
       if (v->xbuf) {
         TTSX_HIP(hipStreamSynchronize(st));
-        if (pl.xbuf_words > v->cap_xbuf) (void)hipFree(v->xbuf), v->xbuf = nullptr, v->cap_xbuf = 0;
+        if (words > v->cap_xbuf) (void)hipFree(v->xbuf), v->xbuf = nullptr, v->cap_xbuf = 0;
       }
       if (!v->xbuf) {
-        TTSX_HIP(hipMalloc(reinterpret_cast<void**>(&v->xbuf), pl.xbuf_words * sizeof(unsigned long long)));
-        v->cap_xbuf = pl.xbuf_words;
+        TTSX_HIP(hipMalloc(reinterpret_cast<void**>(&v->xbuf), words * sizeof(unsigned long long)));
+        v->cap_xbuf = words;
       }
       TTSX_HIP(hipMemsetAsync(v->xbuf, 0, v->cap_xbuf * sizeof(unsigned long long), st));  // tag 0 matches no launch
       v->xtag = 0;
     }
   }
   return enqueue_griffin_lim(v->tw, v->winpad, ybuf, mag, init_phase, n_frames, B, F, &v->sp, iters, preemph, wav, st,
-                             pl.exchange ? v->xbuf : nullptr, &v->xtag);
+                             (pl.exchange || pl.defer) ? v->xbuf : nullptr, &v->xtag);
 }
 
 extern "C" int ttsx_vocoder_stft(ttsx_vocoder* v, const float* y, int B, int F, float* spec_re, float* spec_im,
