@@ -423,7 +423,8 @@ struct GemmOp {
     const int b0 = (wg / ngrp) * (NT * 16);
     // k-groups in flight per wave (deeper prefetch on the big tiles measured slower: 54.0 / 56.4 / 57.2 us per
     // step at 6 / 8 / 10 against 53.4 at 4)
-    constexpr int DMAX = (R * NT >= 4) ? 4 : (NT == 1 && R == 1 ? 8 : 6);
+    // (64 x 64 tiles: three, or the 128 operand registers of four groups push the kernel past 256 and it spills)
+    constexpr int DMAX = (R * NT >= 16) ? 3 : (R * NT >= 4) ? 4 : (NT == 1 && R == 1 ? 8 : 6);
     constexpr int D = KGW < DMAX ? KGW : DMAX;
     constexpr int TILES = R * NT, TPW = (TILES + GEMM_WAVES - 1) / GEMM_WAVES;
     f32x4(*red)[TILES][64];
@@ -1933,6 +1934,9 @@ int gemm_shape(int Bpad, int nrb) {
   if (nrb % 2 == 0 && nrb / 2 * nt_total >= cus) shape = 21;
   if (nrb % 2 == 0 && nt_total % 2 == 0 && nrb / 2 * (nt_total / 2) >= cus) shape = 22;
   if (nrb % 4 == 0 && nt_total % 2 == 0 && nrb / 4 * (nt_total / 2) >= cus) shape = 42;
+  // 64 x 64 (padded batch 256 and above): a third less L2 -> CU traffic than 64 x 32, which is what bounds the LSTM
+  // launches there; its combine buffer (128 KB) lives in dynamic LDS, one workgroup per CU
+  if (nrb % 4 == 0 && nt_total % 4 == 0 && nrb / 4 * (nt_total / 4) >= cus) shape = 44;
   return shape;
 }
 // unit groups of the attention LSTM launch (= workgroups along the row axis): one share of the query each
@@ -1940,6 +1944,8 @@ int query_groups(int B, int Bpad) {
   if (B <= GEMV_MAX_B) return QUERY_DIM / 4;
   return QUERY_DIM / 4 / (gemm_shape(Bpad, QUERY_DIM / 4) / 10);
 }
+
+constexpr size_t GEMM44_LDS_BYTES = sizeof(f32x4) * GEMM_WAVES * 16 * 64;  // combine buffer of a 4 x 4 tile
 
 template <int MODE, int KGW, int PK>
 int launch_gemm(const ttsx_t2_decoder* d, GemmP g, int nrb, bool big, const Piece* pc, hipStream_t st) {
@@ -1956,6 +1962,14 @@ int launch_gemm(const ttsx_t2_decoder* d, GemmP g, int nrb, bool big, const Piec
     case 22: return launch_with_piece<GemmOp<2, 2, KGW, MODE>, PK>(d, g, nrb / 2 * (nt_total / 2), 0, pc, st);
     case 42: return launch_with_piece<GemmOp<4, 2, KGW, MODE>, PK>(d, g, nrb / 4 * (nt_total / 2), 0, pc, st);
     case 24: return launch_with_piece<GemmOp<2, 4, KGW, MODE>, PK>(d, g, nrb / 2 * (nt_total / 4), 0, pc, st);
+    case 44: {
+      typedef GemmOp<4, 4, KGW, MODE, true> Op;
+      TTSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dual_kernel<Op, NoOp>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM44_LDS_BYTES));
+      dual_kernel<Op, NoOp><<<nrb / 4 * (nt_total / 4), GEMM_THREADS, GEMM44_LDS_BYTES, st>>>(g, 0, nrb / 4 * (nt_total / 4));
+      TTSX_LAUNCH_CHECK();
+      return TTSX_OK;
+    }
     default: return launch_with_piece<GemmOp<1, 1, KGW, MODE>, PK>(d, g, nrb * nt_total, 0, pc, st);
   }
 }
