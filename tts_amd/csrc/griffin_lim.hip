@@ -411,10 +411,32 @@ __device__ __forceinline__ void pdft4(f2& a, f2& b, f2& c, f2& d) {
   else b = pk_addpj(d0, d1), d = pk_addmj(d0, d1);
 }
 
-template <bool INV>
+// ZIN: inputs 0, 1, 2, 13, 14 and 15 are zero (forward transform of a frame whose window covers the middle of the
+// transform length only) and their registers are not read: the first stage takes 20 additions instead of 32.
+template <bool INV, bool ZIN = false>
 __device__ __forceinline__ void pdft16(f2 (&v)[16]) {
+  if constexpr (ZIN) {
+    static_assert(!INV, "the pruned first stage is the forward one");
+    {
+      // a = 0
+      const f2 c = v[8], s1 = v[4] + v[12], d1 = v[4] - v[12];
+      v[0] = c + s1, v[8] = c - s1, v[4] = pk_neg_addmj(c, d1), v[12] = pk_neg_addpj(c, d1);
+    }
 #pragma unroll
-  for (int r1 = 0; r1 < 4; ++r1) pdft4<INV>(v[r1], v[r1 + 4], v[r1 + 8], v[r1 + 12]);
+    for (int r1 = 1; r1 < 3; ++r1) {
+      // a = d = 0
+      const f2 b = v[r1 + 4], c = v[r1 + 8];
+      v[r1] = c + b, v[r1 + 8] = c - b, v[r1 + 4] = pk_neg_addmj(c, b), v[r1 + 12] = pk_neg_addpj(c, b);
+    }
+    {
+      // d = 0
+      const f2 b = v[7], s0 = v[3] + v[11], d0 = v[3] - v[11];
+      v[3] = s0 + b, v[11] = s0 - b, v[7] = pk_addmj(d0, b), v[15] = pk_addpj(d0, b);
+    }
+  } else {
+#pragma unroll
+    for (int r1 = 0; r1 < 4; ++r1) pdft4<INV>(v[r1], v[r1 + 4], v[r1 + 8], v[r1 + 12]);
+  }
   // W16^m at positive angle; the forward transform multiplies by the conjugates
   constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, C2 = 0.70710678118654752f;
   const f2 b1 = {C1, S1}, b2 = {C2, C2}, b3 = {S1, C1}, b6 = {-C2, C2}, b9 = {-C1, -S1};
@@ -485,6 +507,10 @@ __device__ __forceinline__ void pfft1024_pass3(f2 (&v)[16], f2* s, const f2* s_t
 struct FrameIn {
   f2 x[16];
 };
+// PRUNE: the window is zero at the sample pairs m < 192 and m >= 832 (r = 0, 1, 2, 13, 14, 15 of every lane), which
+// are neither loaded nor multiplied nor fed to the first pass; and the synthesis side computes only the outputs
+// that the windowed frame keeps (gl_prunable below).
+template <bool PRUNE>
 __device__ __forceinline__ void frame_prefetch(const FrameP& p, int b, int i, int lane, FrameIn& in) {
   const FrameGeom q = p.q;
   int lane_a = lane;
@@ -496,7 +522,7 @@ __device__ __forceinline__ void frame_prefetch(const FrameP& p, int b, int i, in
   const float* src = p.ypad + (size_t)b * q.LP + (size_t)i * q.hop;
   const float* src_hi = src + hi_off;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
+  for (int r = PRUNE ? 3 : 0; r < (PRUNE ? 13 : 16); ++r) {
     // (uniform base + constant, then a 32-bit unsigned lane offset: the scalar-base addressing form)
     // the hop is odd in general: two 4-byte loads
     const float* sr = (r < 8 ? src : src_hi) + 128 * (r & 7);
@@ -504,6 +530,7 @@ __device__ __forceinline__ void frame_prefetch(const FrameP& p, int b, int i, in
   }
 }
 
+template <bool PRUNE>
 __device__ __forceinline__ void frame_iter(const FrameP& p, int b, int i, float2* s_, const float2* s_tw_,
                                            const float2* s_tw2_, int lane, const FrameIn& in, bool mark) {
   const FrameGeom q = p.q;
@@ -526,9 +553,10 @@ __device__ __forceinline__ void frame_iter(const FrameP& p, int b, int i, float2
   // the window at this lane's samples first, then the target magnitudes of its bin pairs (k, 1024 - k), k = lane +
   // 64 c: loads return in order, so the window products wait for the (cached) window only and the magnitudes, which
   // come from HBM, land during the analysis transform
+  constexpr int R0 = PRUNE ? 3 : 0, R1 = PRUNE ? 13 : 16;
   f2 w[16];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) w[r] = ld_at<f2>((r < 8 ? win2 : win_hi) + 64 * (r & 7), (unsigned)(lane_a + z) * 8u);
+  for (int r = R0; r < R1; ++r) w[r] = ld_at<f2>((r < 8 ? win2 : win_hi) + 64 * (r & 7), (unsigned)(lane_a + z) * 8u);
   __builtin_amdgcn_sched_barrier(0);
   f2 mg[8];
   float m512;
@@ -546,9 +574,9 @@ __device__ __forceinline__ void frame_iter(const FrameP& p, int b, int i, float2
   {
     // ---- analysis: z[m] = (x[2m], x[2m+1]) windowed, first radix-16 pass on the prefetched input
 #pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] = in.x[r] * w[r];
+    for (int r = R0; r < R1; ++r) v[r] = in.x[r] * w[r];
     GL_MARK(1);
-    pdft16<false>(v);
+    pdft16<false, PRUNE>(v);
     pfft1024_pass2<false>(v, s, s_tw, lane_a, z);
     pfft1024_pass3<false>(v, s, s_tw, lane_a, z);
     // v[4 c + r] holds bin (lane + 64 c) + 256 r.  Bins below 512 (r < 2) are this lane's own k of the pairs
@@ -629,7 +657,8 @@ __device__ __forceinline__ void frame_iter(const FrameP& p, int b, int i, float2
   for (int c = 0; c < 4; ++c)
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-      wn[4 * c + r] = ld_at<f2>((r < 2 ? win2 : win_hi) + 64 * c + 256 * (r & 1), (unsigned)(lane_s + z) * 8u);
+      if (!(PRUNE && ((r == 0 && c < 3) || (r == 3 && c > 0))))
+        wn[4 * c + r] = ld_at<f2>((r < 2 ? win2 : win_hi) + 64 * c + 256 * (r & 1), (unsigned)(lane_s + z) * 8u);
   __builtin_amdgcn_sched_barrier(0);
   pfft1024_pass3<true>(v, s, s_tw, lane_s, z);
   GL_MARK(4);
@@ -641,6 +670,8 @@ __device__ __forceinline__ void frame_iter(const FrameP& p, int b, int i, float2
     for (int c = 0; c < 4; ++c)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
+        // (PRUNE: m < 192 and m >= 832 lie outside the windowed frame; the last pass's sums for them fall away)
+        if (PRUNE && ((r == 0 && c < 3) || (r == 3 && c > 0))) continue;
         const int m = lane_s + 64 * c + 256 * r;  // complex index -> samples 2m, 2m+1
         const int n = 2 * m - lpe;
         if (n >= 0 && n < WP) *reinterpret_cast<f2*>(dst + n) = v[4 * c + r] * wn[4 * c + r];
@@ -700,7 +731,7 @@ struct FusedP {
   float* stash;
 };
 
-template <int KIND, int PADDED>
+template <int KIND, int PADDED, bool PRUNE = false>
 __global__ __launch_bounds__(64 * FR_PER_WG, 3) void gl_fused_kernel(FusedP P) {
   __shared__ float2 s_tw[TW_ALL];
   __shared__ float2 s_tw2[516];
@@ -774,8 +805,8 @@ __global__ __launch_bounds__(64 * FR_PER_WG, 3) void gl_fused_kernel(FusedP P) {
     if (i < Fb) {
       if constexpr (KIND == K_GL_ITER) {
         FrameIn fin;
-        frame_prefetch(p, b, i, lane, fin);
-        frame_iter(p, b, i, s_data[wave], s_tw, s_tw2, lane, fin, mark);
+        frame_prefetch<PRUNE>(p, b, i, lane, fin);
+        frame_iter<PRUNE>(p, b, i, s_data[wave], s_tw, s_tw2, lane, fin, mark);
       }
       else frame_body<KIND, true>(p, b, i, s_data[wave], s_tw, s_tw2, lane);
     }
@@ -1322,6 +1353,14 @@ GlPlan gl_plan(const ttsx_stft_params* sp, int B, int F) {
   return pl;
 }
 
+// The iteration's frames can skip the sample pairs m < 192 and m >= 832 of the 1024: the window (samples lpad ..
+// lpad + win of the transform length) is zero there on the analysis side, and the synthesis side keeps samples
+// lpad_even .. lpad_even + WP only.
+bool gl_prunable(const FrameGeom& q) {
+  const int lpe = q.lpad & ~1;
+  return q.lpad >= 2 * 192 && q.lpad + q.win <= 2 * 832 && lpe + WP <= 2 * 832;
+}
+
 // `xbuf` / `xtag`: carry words and launch counter of a handle (null: always halo rounds).
 int enqueue_griffin_lim(const float2* tw, const float* winpad, float* const ybuf[2], const float* mag,
                         const float* init_phase, const int32_t* n_frames, int B, int F, const ttsx_stft_params* sp,
@@ -1341,6 +1380,7 @@ int enqueue_griffin_lim(const float2* tw, const float* winpad, float* const ybuf
   const size_t smem = 2 * (size_t)std::max(P.carry_len, 1) * sizeof(float);
   const bool reflect = sp->pad_mode == TTSX_PAD_REFLECT;
   const bool direct = preemph == 0.f;  // without de-emphasis the last launch writes the trimmed signal itself
+  const bool prune = gl_prunable(q);
   int cur = 0;
   P.out = (direct && iters == 0) ? wav : ybuf[cur];
   if (exchange) P.xtag = ++*xtag;
@@ -1355,10 +1395,12 @@ int enqueue_griffin_lim(const float2* tw, const float* winpad, float* const ybuf
     const bool last = it + 1 == iters;
     if (last && direct) {
       P.out = wav;
-      gl_fused_kernel<K_GL_ITER, 0><<<grid, 64 * FR_PER_WG, smem, st>>>(P);
+      if (prune) gl_fused_kernel<K_GL_ITER, 0, true><<<grid, 64 * FR_PER_WG, smem, st>>>(P);
+      else gl_fused_kernel<K_GL_ITER, 0><<<grid, 64 * FR_PER_WG, smem, st>>>(P);
     } else {
       P.out = ybuf[cur ^ 1];
-      gl_fused_kernel<K_GL_ITER, 1><<<grid, 64 * FR_PER_WG, smem, st>>>(P);
+      if (prune) gl_fused_kernel<K_GL_ITER, 1, true><<<grid, 64 * FR_PER_WG, smem, st>>>(P);
+      else gl_fused_kernel<K_GL_ITER, 1><<<grid, 64 * FR_PER_WG, smem, st>>>(P);
     }
     TTSX_LAUNCH_CHECK();
     cur ^= 1;

@@ -19,6 +19,17 @@ __device__ __forceinline__ f2 pk_addpj(f2 a, f2 b) {
   asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,0]" : "=v"(d) : "v"(a), "v"(b));
   return d;
 }
+// -a - i b = (-a.x + b.y, -a.y - b.x) and -a + i b = (-a.x - b.y, -a.y + b.x)
+__device__ __forceinline__ f2 pk_neg_addmj(f2 a, f2 b) {
+  f2 d;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[1,0] neg_hi:[1,1]" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+__device__ __forceinline__ f2 pk_neg_addpj(f2 a, f2 b) {
+  f2 d;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[1,1] neg_hi:[1,0]" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
 // conj(a - i b) = (a.x + b.y, -a.y + b.x)
 __device__ __forceinline__ f2 pk_conj_addmj(f2 a, f2 b) {
   f2 d;
