@@ -268,13 +268,32 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def kfd_gpu_nodes(base="/sys/class/kfd/kfd/topology/nodes"):
+    """GPUs the kernel driver lists, read from sysfs (topology nodes with SIMDs; CPU nodes have none) — no HIP or
+    torch.cuda call, so a process that only asks this has not opened the GPU.  None when the topology is absent."""
+    if not os.path.isdir(base):
+        return None
+    n = 0
+    for node in os.listdir(base):
+        try:
+            with open(os.path.join(base, node, "properties")) as f:
+                for ln in f:
+                    if ln.startswith("simd_count") and int(ln.split()[1]) > 0:
+                        n += 1
+        except (OSError, ValueError, IndexError):
+            pass
+    return n
+
+
 def launch_ranks(a, argv):
     """Start a.gpus fresh child processes, one rank each (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set), wait
-    for them and return the worst exit status.  Runs before this process has made any GPU call; rank 0's JSON
-    line goes to this process's stdout."""
+    for them and return the worst exit status.  This process never touches the GPU (no HIP call, no torch.cuda
+    call): the node's GPU count comes from sysfs, and each rank checks for itself that its device exists.  When
+    a rank fails, the others — which would wait for it at the rendezvous — are ended.  Rank 0's JSON line goes
+    to this process's stdout."""
     if not a.dry_run:
-        n_dev = torch.cuda.device_count()   # (counting devices does not initialise the GPU)
-        if a.gpus > n_dev:
+        n_dev = kfd_gpu_nodes()
+        if n_dev is not None and a.gpus > n_dev:
             sys.stderr.write("bench.py: --gpus %d asked for but this node shows %d GPU(s)\n" % (a.gpus, n_dev))
             return 2
     port = _free_port()
@@ -283,11 +302,18 @@ def launch_ranks(a, argv):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(a.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
-    worst = 0
-    for p in procs:
-        rc = p.wait()
-        if rc != 0:
-            worst = rc if worst == 0 else worst
+    worst, live = 0, list(procs)
+    while live:
+        time.sleep(0.05)
+        for p in list(live):
+            rc = p.poll()
+            if rc is None:
+                continue
+            live.remove(p)
+            if rc != 0 and worst == 0:
+                worst = rc if rc > 0 else 1
+                for q in live:         # exactly the children started above
+                    q.terminate()
     return worst
 
 

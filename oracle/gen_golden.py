@@ -8,6 +8,8 @@ Usage (from the repo root, in the container that mounts /root/reference):
                                         # attention, speaker embedding, inference_truncated)
     python oracle/gen_golden.py t2audio # AudioProcessor pieces that run without librosa
     python oracle/gen_golden.py t1      # Tacotron (v1) model fixtures
+    python oracle/gen_golden.py t2gl    # the reference's own _griffin_lim / inv_mel_spectrogram control flow
+    python oracle/gen_golden.py t1gl    # the same for the Tacotron (v1) tree (inv_spectrogram, reflect padding)
     python oracle/gen_golden.py text    # symbol tables, cleaners, number speller, id sequences
     python oracle/gen_golden.py config  # the three config files as the reference's loaders parse them
 
@@ -23,6 +25,18 @@ placeholder modules are registered for the import statements to succeed.
 No function of those packages is emulated: anything that calls into them
 (stft, istft, filters.mel, the text front-end) stays un-runnable and its
 parity is documented as unpinned.
+
+The one exception are the `t2gl` / `t1gl` families.  There the placeholder
+`librosa` carries three functions — `stft`, `istft`, `filters.mel` — that are
+the restatements of `oracle/audio_oracle.py`, and `numpy.complex` (removed from
+NumPy, used at Tacotron2/TTS/utils.py:924) is set to `complex` in that process,
+so that the reference's OWN `_griffin_lim`, `inv_mel_spectrogram` and
+`inv_spectrogram` run (Tacotron2/TTS/utils.py:896-929, Tacotron/TTS/utils.py:
+169-196).  Those fixtures pin what the reference's code does around the three
+library calls: the 60-iteration loop, the complex128 / complex64 / float32
+dtype trail, `angle(0) = 0`, the mel inversion through `pinv`, the power and
+the de-emphasis.  They do NOT pin librosa: both sides of such a comparison
+share the restated stft / istft / mel filterbank, whose parity stays unpinned.
 """
 import json
 import os
@@ -310,6 +324,103 @@ def gen_t1():
     print("t1_audio_pieces", ap.n_fft, ap.hop_length, ap.win_length)
 
 
+# ------------------------------------------------------------------ the reference's Griffin-Lim control flow
+GL_FRAMES = (12, 173)
+
+
+def _register_restated_librosa():
+    """A placeholder `librosa` whose stft / istft / filters.mel are the restatements of oracle/audio_oracle.py
+    (signatures and defaults of librosa 0.7.2 as the reference calls them), and numpy.complex for NumPy >= 1.24."""
+    from oracle import audio_oracle as ao
+    _register_placeholders()
+    lib = sys.modules["librosa"]
+
+    def stft(y, n_fft=2048, hop_length=None, win_length=None, window="hann", center=True, dtype=np.complex64,
+             pad_mode="reflect"):
+        assert window == "hann" and center and dtype == np.complex64
+        win_length = n_fft if win_length is None else win_length
+        return ao.stft(y, n_fft, win_length // 4 if hop_length is None else hop_length, win_length, pad_mode)
+
+    def istft(stft_matrix, hop_length=None, win_length=None, window="hann", center=True, dtype=np.float32,
+              length=None):
+        assert window == "hann" and center and dtype == np.float32 and length is None
+        n_fft = 2 * (stft_matrix.shape[0] - 1)
+        win_length = n_fft if win_length is None else win_length
+        return ao.istft(stft_matrix, win_length // 4 if hop_length is None else hop_length, win_length)
+
+    def mel(sr, n_fft, n_mels=128, fmin=0.0, fmax=None, htk=False, norm=1):
+        assert not htk and norm == 1
+        return ao.mel_basis(sr, n_fft, n_mels, fmin, fmax)
+    lib.stft, lib.istft = stft, istft
+    lib.filters = types.SimpleNamespace(mel=mel)
+    if not hasattr(np, "complex"):
+        np.complex = complex
+
+
+def _gl_inputs(tag, n_rows, F, lo, hi):
+    """Normalised spectrogram input [n_rows, F] with a silent stretch: frames 3..9 sit at the clipping floor."""
+    x = synthetic.uniform(100 + F, tag, (n_rows, F), lo, hi).astype(np.float32)
+    return x
+
+
+def _gl_magnitudes(tag, F):
+    """Magnitudes for a direct _griffin_lim call; frames 3..9 are exactly zero, so the frames in the middle of
+    that stretch see an all-zero signal and exercise angle(0) = 0."""
+    S = synthetic.uniform(200 + F, tag, (1025, F), 0.0, 2.0).astype(np.float32)
+    S[:, 3:10] = 0.0
+    return S
+
+
+def _gen_gl(tree, audio, seeds, name, use_mel):
+    _register_restated_librosa()
+    sys.path.insert(0, os.path.join(REF, tree))
+    from TTS.utils import AudioProcessor  # the reference implementation
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        ap = AudioProcessor(**audio)
+    out = dict(meta=json.dumps(dict(audio=audio, tree=tree, frames=list(GL_FRAMES), seeds=list(seeds),
+                                    phase="numpy.random.RandomState(seed).rand(1025, F): the stream that "
+                                          "np.random.seed(seed); np.random.rand(1025, F) draws",
+                                    pins="control flow, dtype trail, angle(0)=0, pinv, power, de-emphasis of the "
+                                         "reference; NOT librosa (stft/istft/filters.mel are the oracle's "
+                                         "restatements on both sides)")),
+               params=np.array([ap.n_fft, ap.hop_length, ap.win_length]))
+    for F, seed in zip(GL_FRAMES, seeds):
+        S = _gl_magnitudes(name + ".S", F)
+        np.random.seed(seed)
+        y = ap._griffin_lim(S)                       # reference: Tacotron2/TTS/utils.py:922-929 / Tacotron/...:189-196
+        assert y.dtype == np.float32 and y.shape == (ap.hop_length * (F - 1),), (y.dtype, y.shape)
+        if use_mel:
+            x = _gl_inputs(name + ".mel", 80, F, -4.5, 4.5)
+            np.random.seed(seed + 1)
+            wav = ap.inv_mel_spectrogram(x)          # reference: Tacotron2/TTS/utils.py:905-912
+        else:
+            x = _gl_inputs(name + ".lin", 1025, F, -0.1, 1.1)
+            np.random.seed(seed + 1)
+            wav = ap.inv_spectrogram(x)              # reference: Tacotron/TTS/utils.py:169-177
+        out.update({"S%d" % F: S, "y%d" % F: y, "x%d" % F: x, "wav%d" % F: wav})
+        print(name, "F", F, "y rms %.4f wav rms %.4f" % (float(np.sqrt((y ** 2).mean())), float(np.sqrt((wav ** 2).mean()))),
+              wav.dtype)
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
+
+
+def gen_t2gl():
+    audio = dict(num_mels=80, num_freq=1025, sample_rate=22050, frame_length_ms=50, frame_shift_ms=12.5,
+                 preemphasis=0.98, min_level_db=-100, ref_level_db=20, power=1.5, griffin_lim_iters=60,
+                 signal_norm=True, symmetric_norm=True, max_norm=4, clip_norm=True, mel_fmin=0.0,
+                 mel_fmax=8000.0, do_trim_silence=True)
+    _gen_gl("Tacotron2", audio, (5, 6), "t2gl_reference_loop", use_mel=True)
+
+
+def gen_t1gl():
+    audio = dict(num_mels=80, num_freq=1025, sample_rate=22050, frame_length_ms=50, frame_shift_ms=12.5,
+                 preemphasis=0.98, min_level_db=-100, ref_level_db=20, power=1.5, griffin_lim_iters=60,
+                 signal_norm=True, symmetric_norm=False, max_norm=1, clip_norm=True, mel_fmin=None,
+                 mel_fmax=None, do_trim_silence=True)
+    _gen_gl("Tacotron", audio, (7, 8), "t1gl_reference_loop", use_mel=False)
+
+
 # ------------------------------------------------------------------ text front-end (pure-Python part)
 TEXT_LINES = [
     "Hello, World!  This is   a test.",
@@ -393,4 +504,4 @@ def gen_config():
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     {"t2": gen_t2, "t2long": gen_t2long, "t2v": gen_t2v, "t2audio": gen_t2audio, "t1": gen_t1, "text": gen_text,
-     "config": gen_config}[sys.argv[1]]()
+     "config": gen_config, "t2gl": gen_t2gl, "t1gl": gen_t1gl}[sys.argv[1]]()

@@ -122,3 +122,32 @@ def test_mel_filterbank_has_the_published_slaney_properties():
         mel_pts = audio._mel_to_hz(np.linspace(audio._hz_to_mel(0.0), audio._hz_to_mel(8000.0), 82))
         assert np.abs(freqs[peaks] - mel_pts[1:-1]).max() <= 11025.0 / 1024
     np.testing.assert_array_equal(orc._build_mel_basis(), audio.mel_filterbank(22050, 2048, 80, 0.0, 8000.0))
+
+
+def _gl_cases():
+    for name, cfg, use_mel in (("t2gl_reference_loop.npz", ao.T2_AUDIO, True), ("t1gl_reference_loop.npz", ao.T1_AUDIO, False)):
+        g = np.load(os.path.join(GOLDEN, name))
+        meta = json.loads(str(g["meta"]))
+        for F, seed in zip(meta["frames"], meta["seeds"]):
+            yield name, cfg, use_mel, g, F, seed
+
+
+def test_oracle_replays_the_references_own_griffin_lim_loop():
+    """`t2gl` / `t1gl` fixtures: the reference's `_griffin_lim`, `inv_mel_spectrogram` (Tacotron2/TTS/utils.py:
+    905-929) and `inv_spectrogram` (Tacotron/TTS/utils.py:169-196) themselves, run with np.random.seed(k) and a
+    placeholder librosa whose stft / istft / filters.mel are this oracle's restatements.  Pins the oracle's loop,
+    dtype trail (complex128 product, float32 signal, complex64 spectrum), angle(0) = 0 (frames 3..9 of S are
+    zero), pinv, power and de-emphasis against the reference's code; librosa itself stays PARITY UNPINNED."""
+    for name, cfg, use_mel, g, F, seed in _gl_cases():
+        a = ao.AudioOracle(**cfg)
+        assert [a.n_fft, a.hop_length, a.win_length] == g["params"].tolist()
+        S, y_ref = g["S%d" % F], g["y%d" % F]
+        assert (S[:, 3:10] == 0).all() and y_ref.dtype == np.float32
+        y = a._griffin_lim(S, np.random.RandomState(seed).rand(1025, F))
+        assert y.dtype == np.float32 and y.shape == y_ref.shape == (a.hop_length * (F - 1),)
+        assert np.abs(y - y_ref).max() <= 1e-6 * max(1.0, np.abs(y_ref).max()), (name, F)
+        ph = np.random.RandomState(seed + 1).rand(1025, F)
+        wav = a.inv_mel_spectrogram(g["x%d" % F], ph) if use_mel else a.inv_spectrogram(g["x%d" % F], ph)
+        wav_ref = g["wav%d" % F]
+        assert wav.dtype == wav_ref.dtype == np.float64
+        assert np.abs(wav - wav_ref).max() <= 1e-6 * np.abs(wav_ref).max(), (name, F)

@@ -145,3 +145,42 @@ def test_corpus_texts_do_not_depend_on_the_cut():
     assert all(t.min() >= 3 and t.max() < 129 for t in texts)
     again = corpus.corpus_texts(lengths, seed=3)
     assert all((a == b).all() for a, b in zip(texts, again))
+
+
+def test_launcher_parent_counts_gpus_from_sysfs_and_never_asks_the_runtime(tmp_path, monkeypatch):
+    """The process that starts the ranks must not open the GPU (a process that has and then starts children is
+    refused on the GPU pool): its device count comes from the driver's sysfs topology, not from torch.cuda."""
+    import argparse
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, ROOT)
+    import bench
+    for node, simds in (("0", 0), ("1", 0), ("2", 1024), ("3", 1024)):
+        d = tmp_path / node
+        d.mkdir()
+        (d / "properties").write_text("cpu_cores_count %d\nsimd_count %d\n" % (0 if simds else 64, simds))
+    assert bench.kfd_gpu_nodes(str(tmp_path)) == 2
+    assert bench.kfd_gpu_nodes(str(tmp_path / "absent")) is None
+
+    def forbidden(*a, **k):
+        raise AssertionError("the launcher parent asked the GPU runtime")
+    for name in ("device_count", "is_available", "init", "set_device", "current_device"):
+        monkeypatch.setattr(torch.cuda, name, forbidden)
+    started = []
+
+    class FakeProc:
+        def __init__(self, argv, env):
+            started.append((argv, env["RANK"], env["WORLD_SIZE"], env["MASTER_ADDR"]))
+            self.rank = int(env["RANK"])
+
+        def poll(self):
+            return 3 if self.rank == 1 else None if self.rank == 0 and not getattr(self, "ended", False) else -15
+
+        def terminate(self):
+            self.ended = True
+    monkeypatch.setattr(bench.subprocess, "Popen", lambda argv, env: FakeProc(argv, env))
+    monkeypatch.setattr(bench, "kfd_gpu_nodes", lambda: 8)
+    rc = bench.launch_ranks(argparse.Namespace(gpus=2, dry_run=False), ["--gpus", "2"])
+    assert rc == 3 and [s[1:] for s in started] == [("0", "2", "127.0.0.1"), ("1", "2", "127.0.0.1")]
+    monkeypatch.setattr(bench, "kfd_gpu_nodes", lambda: 1)
+    assert bench.launch_ranks(argparse.Namespace(gpus=2, dry_run=False), []) == 2 and len(started) == 2

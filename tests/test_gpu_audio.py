@@ -303,3 +303,28 @@ def test_two_vocoder_handles_on_two_streams_give_the_same_samples():
     assert float(one.abs().max()) > 0
     for h in handles:
         assert lib.ttsx_vocoder_destroy(h) == _lib.OK
+
+
+@pytest.mark.parametrize("name,v1", [("t2gl_reference_loop.npz", False), ("t1gl_reference_loop.npz", True)])
+def test_griffin_lim_against_the_references_own_loop(name, v1):
+    """Fixtures produced by the reference's `_griffin_lim` / `inv_mel_spectrogram` / `inv_spectrogram` themselves
+    (seeded global NumPy RNG; the three librosa calls inside them were the oracle's restatements, so this pins the
+    loop around them - 60 iterations, angle(0) = 0 on the silent frames 3..9, pinv, power, de-emphasis - and not
+    librosa).  Waveform SNR >= 40 dB from the same initial phase."""
+    import json
+    import os
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, name))
+    meta = json.loads(str(g["meta"]))
+    _, ap = _aps(v1, iters=60)
+    assert [ap.n_fft, ap.hop_length, ap.win_length] == g["params"].tolist()
+    for F, seed in zip(meta["frames"], meta["seeds"]):
+        y = ap._griffin_lim(g["S%d" % F], init_phase=np.random.RandomState(seed).rand(1025, F))
+        assert y.shape == g["y%d" % F].shape
+        snr = _snr_db(g["y%d" % F], y)
+        assert snr >= 40.0, "%s F=%d _griffin_lim SNR %.1f dB" % (name, F, snr)
+        ph = np.random.RandomState(seed + 1).rand(1025, F)
+        wav = ap.inv_spectrogram(g["x%d" % F], init_phase=ph) if v1 else ap.inv_mel_spectrogram(g["x%d" % F], init_phase=ph)
+        assert wav.dtype == np.float64 and wav.shape == g["wav%d" % F].shape
+        snr = _snr_db(g["wav%d" % F], wav)
+        assert snr >= 40.0, "%s F=%d end-to-end SNR %.1f dB" % (name, F, snr)
