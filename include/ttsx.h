@@ -44,6 +44,12 @@ extern "C" {
 #define TTSX_PAD_REFLECT 1
 
 const char* ttsx_last_error_string(void);
+/* Interface version of the loaded library; a caller compares it with the TTSX_VERSION it was built against.
+ *   1  first interface
+ *   2  ttsx_request_tail's `offsets` buffer holds B + 2 ints (the device keeps the peak word at [B + 1]; it was
+ *      B + 1); ttsx_t2_decoder_run zero-fills rows between an utterance's own stop and *steps_run_host when one or
+ *      two utterances end at their own stop frames */
+#define TTSX_VERSION 2
 int ttsx_version(void);
 
 /* ------------------------------------------------------------------ Tacotron2 decoder
@@ -138,8 +144,10 @@ int ttsx_t2_decoder_set_initial(ttsx_t2_decoder* dec, int keep_states, const flo
  *   n_steps  [B] int32              steps until (and including) the first stop frame,
  *                                   or the number of steps run if it never fired
  *   steps_run_host  host int: number of decoder steps executed (max over b)
- * Rows past an utterance's n_steps are whatever a run that kept stepping
- * produced; rows past *steps_run_host are not written.  Synchronises `stream`. */
+ * Rows past an utterance's n_steps and below *steps_run_host are either what a
+ * run that kept stepping produced (batches that step together) or zero (one or
+ * two utterances on the persistent kernels, which end at their own stop
+ * frame); rows past *steps_run_host are not written.  Synchronises `stream`. */
 int ttsx_t2_decoder_run(ttsx_t2_decoder* dec, const float* enc, const int32_t* enc_len, int B, int T,
                         int r, int max_steps, float stop_threshold, int fixed_steps, float* mel,
                         float* align, float* stop, int32_t* n_steps, int* steps_run_host, void* stream);

@@ -17,7 +17,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), name
     assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
-    assert lib.ttsx_version() >= 1
+    assert lib.ttsx_version() == 2
 
 
 def test_struct_layouts_match_header():

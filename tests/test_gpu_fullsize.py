@@ -233,3 +233,51 @@ def test_staged_corpus_two_ranks_equal_one_rank_and_batch1(model):
     solo = m.inference_batch(torch.as_tensor(texts[i][None]), fixed_steps=steps)
     err = np.abs(solo["postnet_output"][0].cpu().numpy() - ref[i][0]).max(-1)
     assert err[:LONG_FREE].max() < 1e-3 and err.max() < 0.2
+
+
+def test_corpus_share_as_benchmarked_batches_of_256(model):
+    """The share the benchmark's `corpus` block times: rank 0 of 8 of the 4096-utterance corpus in length-sorted
+    batches of 256 (two batches, 512 utterances; ragged lengths, the 64 x 64 LSTM tiles and the wide fused
+    attention kernel).  Held bit-equal to the same two batches run by two other ranks (the ranks of a
+    sixteen-way deal that own them), and three rows of the first batch - longest, median, shortest text -
+    follow the CPU oracle's batch-1 run over their first 200 steps (independent utterances:
+    Tacotron2/TTS/synthesizer.py:147-170)."""
+    from oracle import t2_oracle
+    from tts_amd import corpus
+    m, ap, sd = model
+    lengths = corpus.corpus_lengths(4096, seed=1234)
+    texts = corpus.corpus_texts(lengths, seed=1234)
+    kw = dict(batch=256, policy="lpt", steps_per_id=6, max_steps=3000)
+    share = corpus.StagedCorpus(m, ap, lengths, texts, world=8, rank=0, **kw)
+    mine = [it["batch_index"] for it in share.items]
+    assert share.n_utts == 512 and len(mine) == 2
+    ref = share.run(keep=True)
+    assert len(ref) == 512
+    first = share.items[0]["idx"]
+    del share
+    torch.cuda.empty_cache()
+    # sixteen batches over sixteen ranks: one batch each; the two ranks that own this share's batches
+    dealt = corpus.deal(corpus.plan_batches(lengths, 256), lengths, 16, "lpt")
+    owners = [r for r in range(16) if dealt[r][0] in mine]
+    assert all(len(d) == 1 for d in dealt) and len(owners) == 2
+    seen = {}
+    for r in owners:
+        part = corpus.StagedCorpus(m, ap, lengths, texts, world=16, rank=r, **kw)
+        got = part.run(keep=True)
+        assert not (set(got) & set(seen))
+        seen.update(got)
+        del part
+        torch.cuda.empty_cache()
+    assert sorted(seen) == sorted(ref)
+    for i in ref:
+        F = 6 * int(lengths[i])
+        assert ref[i][0].shape == (F, 80) and ref[i][1].shape == (275 * (F - 1),)
+        assert np.array_equal(ref[i][0], seen[i][0]) and np.array_equal(ref[i][1], seen[i][1]), i
+        assert np.isfinite(ref[i][1]).all()
+    n = 200
+    for i in (int(first[0]), int(first[len(first) // 2]), int(first[-1])):
+        orc = t2_oracle.inference(sd, texts[i][None], r=1, attn_norm="sigmoid", prenet_type="bn", max_steps=n,
+                                  fixed_steps=True)
+        # (the oracle's postnet sees 200 frames only: its last rows lack the right-hand conv context)
+        err = np.abs(ref[i][0][:n - 12] - orc["postnet_output"][0, :n - 12].numpy()).max()
+        assert err < 1e-3, (i, int(lengths[i]), err)

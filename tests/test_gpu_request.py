@@ -177,3 +177,50 @@ def test_two_request_threads_with_their_own_models():
         for k in range(4):
             np.testing.assert_array_equal(got[s][k][0], alone[s][0])
             np.testing.assert_array_equal(got[s][k][1], alone[s][1])
+
+
+def test_short_lived_request_threads_do_not_accumulate_vocoder_handles():
+    """A threaded server starts a thread per request (Flask's app.run, Tacotron2/Tacotron2.py:59): threads that come and go,
+    each with a stream of its own, one Griffin-Lim call each through one shared AudioProcessor.  The handles
+    are pooled, so their number stays bounded and the free device memory stays where it was."""
+    import threading
+    from tts_amd import synthetic
+    from tts_amd.audio import AudioProcessor
+    from oracle import audio_oracle as ao
+    kw = {k: v for k, v in ao.T2_AUDIO.items() if k not in ("pad_mode", "win_from_hop")}
+    kw["griffin_lim_iters"] = 2
+    ap = AudioProcessor(verbose=False, **kw)
+    F = 400
+    mel = synthetic.normal(5, "pool.mel", (80, F), 0.0, 1.0).astype(np.float32)
+    ph = synthetic.gl_init_phase(6, 1025, F)
+    want = ap.inv_mel_spectrogram(mel, init_phase=ph)
+    errs = []
+
+    def request(own_stream):
+        try:
+            if own_stream:
+                with torch.cuda.stream(torch.cuda.Stream()):
+                    got = ap.inv_mel_spectrogram(mel, init_phase=ph)
+            else:
+                got = ap.inv_mel_spectrogram(mel, init_phase=ph)
+            np.testing.assert_array_equal(got, want)
+        except Exception as e:
+            errs.append(e)
+
+    def burst(n, own_stream):
+        for _ in range(n):
+            t = threading.Thread(target=request, args=(own_stream,))
+            t.start()
+            t.join()
+    burst(40, True)      # (past torch's pool of 32 streams per device: every stream the threads can get exists now)
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()        # (torch caches blocks per stream; only the library's own allocations are of interest)
+    free0 = torch.cuda.mem_get_info()[0]
+    burst(20, True)
+    burst(20, False)
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert not errs, errs
+    assert len(ap._handles) <= ap.MAX_IDLE_VOCODERS + 1, len(ap._handles)
+    assert free0 - free1 < 8 << 20, "device memory grew by %.1f MB over forty request threads" % ((free0 - free1) / 2 ** 20)

@@ -147,6 +147,9 @@ class TtsxError(RuntimeError):
     pass
 
 
+VERSION = 2   # TTSX_VERSION of include/ttsx.h (2: request_tail offsets [B + 2], zero-filled tail rows)
+
+
 def load():
     """Load libttsx.so (once) and attach prototypes.  Raises if it is absent:
     the kernels are the product, there is nothing to fall back to."""
@@ -162,6 +165,9 @@ def load():
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
+        if lib.ttsx_version() != VERSION:
+            raise TtsxError("%s has interface version %d, this package was written against %d: rebuild it"
+                            % (LIB_PATH, lib.ttsx_version(), VERSION))
         _lib = lib
     return _lib
 

@@ -14,6 +14,7 @@ run can be reproduced; when omitted the phase comes from `np.random.rand`, as
 in the reference (utils.py:923).  `tacotron_v1=True` selects the Tacotron
 tree's STFT parameters (win_length from frame_length_ms, reflect padding).
 """
+import contextlib
 import ctypes
 import io
 import threading
@@ -91,8 +92,10 @@ class AudioProcessor(object):
                 print("\t | > {}:{}".format(key, value))
         self._device = device
         self._inv_basis_dev = None
-        self._tls = threading.local()       # one vocoder handle per calling thread (a handle serves one caller at a time)
-        self._handles = []
+        # vocoder handles (a handle serves one caller at a time): a pool, not one per thread, so that a server
+        # whose request threads come and go keeps as many handles as it ever had calls in flight at once
+        self._handles = []                  # every handle this object has created (destroyed with it)
+        self._idle = {}                     # stream -> handles not in use whose last work went to that stream
         self._handles_mu = threading.Lock()
         weakref.finalize(self, _destroy_vocoders, self._handles, self._handles_mu)
 
@@ -179,21 +182,44 @@ class AudioProcessor(object):
         return _lib.StftParams(self.n_fft, self.hop_length, self.win_length,
                                _lib.PAD_REFLECT if self.tacotron_v1 else _lib.PAD_CONSTANT)
 
+    MAX_IDLE_VOCODERS = 8
+
+    @contextlib.contextmanager
     def _vocoder(self):
-        """The calling thread's vocoder handle (tables + scratch on this AudioProcessor's device), created on
-        first use.  Request threads that share an AudioProcessor get a handle each, so their Griffin-Lim calls
+        """A vocoder handle (tables + scratch on this AudioProcessor's device) for the duration of one call,
+        taken from the pool of idle handles or created.  Calls are stream-ordered and return before the GPU has
+        finished, so an idle handle is only handed to a caller on the stream its last work went to; callers
+        that overlap in time or use different streams get handles of their own, and their Griffin-Lim calls
         can overlap on the GPU."""
-        h = getattr(self._tls, "handle", None)
+        stream = _lib.current_stream()
+        key = stream.value or 0
+        with self._handles_mu:
+            idle = self._idle.get(key)
+            h = idle.pop() if idle else None
         if h is None:
             lib = _lib.load()
             h = ctypes.c_void_p()
             with torch.cuda.device(self._dev()):
-                _lib.check(lib.ttsx_vocoder_create(self._stft_params(), _lib.current_stream(), ctypes.byref(h)),
+                _lib.check(lib.ttsx_vocoder_create(self._stft_params(), stream, ctypes.byref(h)),
                            "ttsx_vocoder_create")
-            self._tls.handle = h
             with self._handles_mu:
                 self._handles.append(h)
-        return h
+        try:
+            yield h
+        finally:
+            evict = None
+            with self._handles_mu:
+                self._idle.setdefault(key, []).append(h)
+                # streams come and go with their threads: beyond MAX_IDLE_VOCODERS idle handles, the one that
+                # has been idle on another stream the longest is destroyed (destroying waits for its work)
+                if sum(len(v) for v in self._idle.values()) > self.MAX_IDLE_VOCODERS:
+                    other = next((k for k, v in self._idle.items() if v and k != key), key)
+                    evict = self._idle[other].pop(0)
+                    if not self._idle[other]:
+                        del self._idle[other]
+                    self._handles[:] = [x for x in self._handles if x is not evict]
+            if evict is not None:
+                _lib.load().ttsx_vocoder_destroy(evict)
 
     def _audio_params(self):
         return _lib.AudioParams(int(bool(self.signal_norm)), int(bool(self.symmetric_norm)),
@@ -231,8 +257,8 @@ class AudioProcessor(object):
         pre = float(self.preemphasis) if (deemphasis and self.preemphasis != 0) else 0.0
         if mag.device != self._dev():
             raise ValueError("magnitudes live on %s, this AudioProcessor on %s" % (mag.device, self._dev()))
-        with torch.cuda.device(mag.device):
-            _lib.check(lib.ttsx_vocoder_griffin_lim(self._vocoder(), _lib.ptr(mag), _lib.ptr(init_phase),
+        with torch.cuda.device(mag.device), self._vocoder() as voc:
+            _lib.check(lib.ttsx_vocoder_griffin_lim(voc, _lib.ptr(mag), _lib.ptr(init_phase),
                                                     _lib.ptr(n_frames), B, Fr, int(self.griffin_lim_iters), pre,
                                                     _lib.ptr(wav), _lib.current_stream()), "ttsx_vocoder_griffin_lim")
         return wav
@@ -307,8 +333,8 @@ class AudioProcessor(object):
         yd = torch.from_numpy(y).to(self._dev()).unsqueeze(0).contiguous()
         re = torch.empty(1, Fr, self.num_freq, device=yd.device)
         im = torch.empty_like(re)
-        with torch.cuda.device(yd.device):
-            _lib.check(lib.ttsx_vocoder_stft(self._vocoder(), _lib.ptr(yd), 1, Fr, _lib.ptr(re), _lib.ptr(im),
+        with torch.cuda.device(yd.device), self._vocoder() as voc:
+            _lib.check(lib.ttsx_vocoder_stft(voc, _lib.ptr(yd), 1, Fr, _lib.ptr(re), _lib.ptr(im),
                                              _lib.current_stream()), "ttsx_vocoder_stft")
         return (re[0].cpu().numpy() + 1j * im[0].cpu().numpy()).T.astype(np.complex64)
 
@@ -320,8 +346,8 @@ class AudioProcessor(object):
         re = torch.from_numpy(np.ascontiguousarray(Y.real.T.astype(np.float32))).to(self._dev()).unsqueeze(0)
         im = torch.from_numpy(np.ascontiguousarray(Y.imag.T.astype(np.float32))).to(self._dev()).unsqueeze(0)
         y = torch.empty(1, self.hop_length * (Fr - 1), device=re.device)
-        with torch.cuda.device(re.device):
-            _lib.check(lib.ttsx_vocoder_istft(self._vocoder(), _lib.ptr(re), _lib.ptr(im), 1, Fr, _lib.ptr(y),
+        with torch.cuda.device(re.device), self._vocoder() as voc:
+            _lib.check(lib.ttsx_vocoder_istft(voc, _lib.ptr(re), _lib.ptr(im), 1, Fr, _lib.ptr(y),
                                               _lib.current_stream()), "ttsx_vocoder_istft")
         return y[0].cpu().numpy()
 

@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <chrono>
 #include <mutex>
 
 #include "../../include/ttsx.h"
@@ -47,6 +48,32 @@ struct ScopeExit {
     if (armed) f();
   }
   void dismiss() { armed = false; }
+};
+
+// Waits of the persistent team kernels are bounded in wall-clock time, not in polling rounds: a workgroup that has
+// not seen its inputs TEAM_WAIT_TICKS after its 1024th polling round (the 100 MHz constant clock; 50 ms - a step of
+// a resident team takes microseconds) raises the abort word, and the host falls back to the launch chain.
+constexpr long long TEAM_WAIT_TICKS = 5000000;
+__device__ static inline bool team_wait_expired(long spin, long long& t0) {
+  if ((spin & 1023) != 1023) return false;
+  const long long now = wall_clock64();
+  if (spin == 1023) {
+    t0 = now;
+    return false;
+  }
+  return now - t0 > TEAM_WAIT_TICKS;
+}
+
+// After a team run that timed out (its workgroups were not resident together: another process or a long kernel
+// held CUs) the default plan uses the launch chain and tries the team again once this many seconds have passed.
+constexpr double TEAM_COOL_DOWN_S = 5.0;
+struct TeamCoolDown {
+  std::chrono::steady_clock::time_point until{};
+  bool cooling() const { return std::chrono::steady_clock::now() < until; }
+  void start() {
+    until = std::chrono::steady_clock::now() +
+            std::chrono::duration_cast<std::chrono::steady_clock::duration>(std::chrono::duration<double>(TEAM_COOL_DOWN_S));
+  }
 };
 
 __host__ __device__ static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

@@ -16,7 +16,7 @@ void ttsx_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* ttsx_last_error_string(void) { return g_err; }
-extern "C" int ttsx_version(void) { return 1; }
+extern "C" int ttsx_version(void) { return TTSX_VERSION; }
 
 // One team kernel at a time per process: a team needs most of the chip's CUs resident together, and two teams that
 // were dispatched into each other would both wait for CUs the other holds until their bounded waits give up.

@@ -529,7 +529,7 @@ struct ttsx_t1 {
   t1_steps* steps;  // decoder as a chain of launches over the whole chip (null: memory queue too long for it)
   t1_team* team;    // decoder as one persistent launch with on-chip weights, batch 1-2 (null: other geometry)
   int plan;         // ttsx_t1_set_plan: -1 by shape, 0 launch chain, 1 team kernel, 2 one workgroup per utterance
-  bool team_gave_up;  // a team run timed out waiting for co-residency: the default plan uses the launch chain from then on
+  TeamCoolDown team_cool;  // a team run timed out waiting for co-residency: the default plan uses the launch chain for a while
   Layer enc_pre[2], annot, last;
   Cbhg enc_cbhg, post_cbhg;
   // decoder weights (own copies, reference layouts)
@@ -700,13 +700,14 @@ extern "C" int ttsx_t1_decoder_run(ttsx_t1* m, const float* enc, const int32_t* 
   // (t1_steps, in t2_decoder.hip); a memory queue longer than 512 floats leaves only the
   // one-workgroup-per-utterance kernel below.  ttsx_t1_set_plan overrides the choice where the shapes allow.
   const bool team_ok = t1_team_supports(m->team, B, T);
-  if (team_ok && (m->plan == 1 || (m->plan == -1 && !m->team_gave_up))) {
+  if (team_ok && (m->plan == 1 || (m->plan == -1 && !m->team_cool.cooling()))) {
     rc = t1_team_run(m->team, enc, m->ws_annot, lengths, B, T, max_decoder_steps, mel, align, stop, n_steps,
                      steps_run_host, st);
     // TTSX_ERR_STATE: the team did not become resident together (other kernels held the CUs) and its bounded waits
-    // gave up.  Under the default plan the handle then stays with the launch chain, which rewrites every output.
+    // gave up.  Under the default plan the launch chain rewrites every output, and the handle tries the team again
+    // after a cool-down.
     if (rc != TTSX_ERR_STATE || m->plan == 1 || !m->steps) return rc;
-    m->team_gave_up = true;
+    m->team_cool.start();
   }
   if (m->steps && m->plan != 2)
     return t1_steps_run(m->steps, enc, m->ws_annot, lengths, B, T, max_decoder_steps, mel, align, stop, n_steps,

@@ -44,7 +44,6 @@ constexpr int TEAM = TG + 1;      // + the attention workgroup
 constexpr int NT = 512;
 constexpr int MEM = 400, ODIM = 160, PRE0 = 256, PRE1 = 128, RNN = 256, ENC = 256, ATT = 128;
 constexpr int LOCF = 32, LOCK = 31, LPAD = 15, TMAX = 128;
-constexpr long SPIN_LIMIT = 4000000;
 
 // ---- per-thread register image: slot s of thread tid of row workgroup g at img[(g * NS + s) * NT + tid]
 enum {
@@ -125,12 +124,10 @@ __device__ __forceinline__ void publish_row(u64* X, int first, const float* vals
 // words of the wave carry `tag`.  False: aborted (the caller must still reach the barrier that follows).
 // (Keeping two or three reads in flight a fraction of a round trip apart, to see a word sooner, measured slower:
 // 18.6 and 19.1 against 16.4 us per step - more polling reads delay the publishing stores.)
-#ifndef POLL_SLEEP
-#define POLL_SLEEP 1
-#endif
 template <bool SECOND>
 __device__ __forceinline__ bool poll(const u64* a, bool active, const u64* a2, unsigned tag, float* val, float* val2,
                                      int* abort_word) {
+  long long t_wait = 0;
   for (long spin = 0;; ++spin) {
     u64 v = (u64)tag << 32, v2 = (u64)tag << 32;
     if (active) v = __hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -140,11 +137,11 @@ __device__ __forceinline__ bool poll(const u64* a, bool active, const u64* a2, u
     if (SECOND) *val2 = __uint_as_float((unsigned)v2);
     if (__all(ok)) return true;
     if ((spin & 127) == 127 && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
-    if (spin > SPIN_LIMIT) {
+    if (team_wait_expired(spin, t_wait)) {
       __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       return false;
     }
-    __builtin_amdgcn_s_sleep(POLL_SLEEP);
+    __builtin_amdgcn_s_sleep(1);
   }
 }
 
@@ -570,6 +567,7 @@ __device__ void attention_workgroup(const TeamP& p, int b, float* sm) {
       const u64* Q = X + X_QS + cur * X_QS_N + (size_t)(8 * tg) * ATT + d;
       float val[8];
       bool fail = false;
+      long long t_wait = 0;
       for (long spin = 0;; ++spin) {
         bool ok = true;
 #pragma unroll
@@ -580,7 +578,7 @@ __device__ void attention_workgroup(const TeamP& p, int b, float* sm) {
         }
         if (__all(ok)) break;
         if ((spin & 127) == 127 && __hip_atomic_load(ab, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) fail = true;
-        if (spin > SPIN_LIMIT) {
+        if (team_wait_expired(spin, t_wait)) {
           __hip_atomic_store(ab, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           fail = true;
         }
@@ -847,11 +845,7 @@ int t1_team_run(t1_team* t, const float* enc, const float* annot, const int32_t*
   if (t->cap_B < B) {
     if (t->xch) (void)hipFree(t->xch);
     t->xch = nullptr, t->cap_B = 0;
-#ifdef TEAM_XCH_FINE
-    TTSX_HIP(hipExtMallocWithFlags(reinterpret_cast<void**>(&t->xch), sizeof(u64) * (size_t)B * X_TEAM, hipDeviceMallocFinegrained));
-#else
     TTSX_HIP(hipMalloc(reinterpret_cast<void**>(&t->xch), sizeof(u64) * (size_t)B * X_TEAM));
-#endif
     t->cap_B = B;
   }
   std::lock_guard<std::mutex> one_team(ttsx_team_mutex());  // until the synchronisation below

@@ -533,7 +533,7 @@ struct GemmOp {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0)
           __hip_atomic_store(p.x1_flags + (b0 / 16) * (PRENET_DIM / 16) + xb,
-                             (unsigned)(p.ctx->base + p.step_in_chunk + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                             (unsigned)(p.ctx->base + p.step_in_chunk + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
     if (qshare) {
@@ -697,6 +697,8 @@ struct Prenet2AfterProjOp {
       if (lane == 0) cx->sync_failed = 1;
       return;
     }
+    // pairs with the release store of the flags: the x1 reads below are ordered after the flag reads
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     // B fragments: lane l holds x1[16 kg + 4 (l >> 4) + s][b0 + (l & 15)], s = 0..3 (one quad of the quad layout)
     const unsigned long long* X = reinterpret_cast<const unsigned long long*>(p.seg[0].x[0]) +
                                   ((size_t)(lane >> 4) * p.Bpad + b0 + (lane & 15)) * 2;
@@ -1687,10 +1689,11 @@ struct ttsx_t2_decoder {
   bool share_q;  // three-launch attention without the query launch: the energies op adds up the query shares
   unsigned* x1_flags;  // [Bpad / 16][16] step tags of the prenet layer-1 row blocks (Prenet2AfterProjOp)
   int plan_fuse_p2;    // ttsx_t2_decoder_set_fusion: prenet layer 2 of the next step inside the projection launch
+  bool fuse_gave_up;   // a prenet workgroup of that launch once waited too long: the default plan no longer fuses
   // one utterance, short text, plain attention: the whole run as one persistent launch with the weights on chip
   t2_team* team;
   int plan_team;      // ttsx_t2_decoder_set_team: -1 by shape (default), 0 never, 1 wherever the shapes allow
-  bool team_gave_up;  // a team run timed out waiting for its workgroups: the default plan stays with the launch chain
+  TeamCoolDown team_cool;  // a team run timed out waiting for its workgroups: the default plan uses the launch chain for a while
 };
 
 namespace {
@@ -2095,7 +2098,7 @@ int enqueue_step(ttsx_t2_decoder* d, int i, bool first, bool more, hipStream_t s
   // (measured per step, own launch / fused, T=128 unless noted: B=32 38.7 / 39.9 us, B=48 48.1 / 46.9, B=64 48.2 /
   // 46.6, B=64 T=256 52.2 / 50.9, B=64 T=64 (no split) 49.1 / 51.4, B=128 (no split) 73.3 / 76.4: it pays where the
   // early/late split is on at padded batch 64, and costs where the fused launch has no piece work to hide behind)
-  const bool fuse_p2 = mfma && (d->plan_fuse_p2 == 1 || (d->plan_fuse_p2 == -1 && split && Bpad == 64));
+  const bool fuse_p2 = mfma && (d->plan_fuse_p2 == 1 || (d->plan_fuse_p2 == -1 && !d->fuse_gave_up && split && Bpad == 64));
   // (pieces of the attention partial: thirds of the rows behind decoder LSTM / projection / prenet at batch 1-2;
   // on the MFMA engine the two halves of K behind projection / prenet)
   pc = mfma ? k_piece(pa, 1) : pa.piece(2);
@@ -2258,7 +2261,7 @@ int push_ctx(ttsx_t2_decoder* d, hipStream_t st) {
 int launch_chunk(ttsx_t2_decoder* d, int n, int chunk, hipStream_t st) {
   if (n == chunk) {
     ttsx_t2_decoder::ChunkGraph& g = d->graphs[chunk == CHUNK ? 0 : 1];   // (the cache key includes the chunk size)
-    const int split = (int)d->split + 2 * (int)d->share_q + 4 * (d->plan_fuse_p2 + 1);
+    const int split = (int)d->split + 2 * (int)d->share_q + 4 * (d->plan_fuse_p2 + 1) + 16 * (int)d->fuse_gave_up;
     const bool cached = g.exec && g.B == d->B && g.T == d->T && g.r == d->rc_host->r && g.gen == d->ws_gen &&
                         g.chunk == n && g.split == split && g.fused == (int)d->fused;
     if (!cached) {
@@ -2681,18 +2684,26 @@ extern "C" int ttsx_t2_decoder_run(ttsx_t2_decoder* d, const float* enc, const i
   // (t2_team.hip; 11.7 us per step against 31.7 for the chain at batch 1, and two such runs one after the other
   // still beat the chain's 35 us per step at batch 2).
   if (B <= 2 && t2_team_supports(d->team, 1, T, r) && !carried && !d->variant && d->graves_K == 0 &&
-      (d->plan_team == 1 || (d->plan_team == -1 && !d->team_gave_up))) {
+      (d->plan_team == 1 || (d->plan_team == -1 && !d->team_cool.cooling()))) {
     T2TeamState so{};
     so.h_a = d->h_a[0], so.h_a_alt = d->h_a[1], so.c_a = d->c_a, so.h_d = d->h_d[0], so.h_d_alt = d->h_d[1];
     so.c_d = d->c_d, so.ctx = d->ctx, so.x1 = d->x1;
-    int run = 0;
+    int run = 0, run_of[2] = {0, 0};
     for (int b = 0; b < B && rc == TTSX_OK; ++b) {
-      int run_b = 0;
       rc = t2_team_run(d->team, d->enc_ws + (size_t)b * T * ENC_DIM, d->P + (size_t)b * T * ATT_DIM, d->len_ws + b, T, r,
                        max_steps, stop_threshold, fixed_steps, d->norm, mel + (size_t)b * max_steps * r * MEL_DIM,
                        align + (size_t)b * max_steps * T, stop + (size_t)b * max_steps, n_steps + b,
-                       B == 1 ? &so : nullptr, &run_b, st);
-      run = std::max(run, run_b);
+                       B == 1 ? &so : nullptr, &run_of[b], st);
+      run = std::max(run, run_of[b]);
+    }
+    // Two utterances are two runs, each ending at its own stop frame: the rows of the earlier one between its
+    // stop and the later one's are zero-filled, so that everything below *steps_run_host is defined.
+    for (int b = 0; b < B && rc == TTSX_OK; ++b) {
+      const size_t a = run_of[b], n = (size_t)run - a;
+      if (n == 0) continue;
+      TTSX_HIP(hipMemsetAsync(mel + ((size_t)b * max_steps + a) * r * MEL_DIM, 0, sizeof(float) * n * r * MEL_DIM, st));
+      TTSX_HIP(hipMemsetAsync(align + ((size_t)b * max_steps + a) * T, 0, sizeof(float) * n * T, st));
+      TTSX_HIP(hipMemsetAsync(stop + (size_t)b * max_steps + a, 0, sizeof(float) * n, st));
     }
     if (rc == TTSX_OK) {
       if (steps_run_host) *steps_run_host = run;
@@ -2701,9 +2712,9 @@ extern "C" int ttsx_t2_decoder_run(ttsx_t2_decoder* d, const float* enc, const i
       return TTSX_OK;
     }
     // TTSX_ERR_STATE: the team did not become resident together and its bounded waits gave up.  Under the default
-    // plan the handle then stays with the launch chain, which starts over from a fresh state.
+    // plan the launch chain starts over from a fresh state, and the handle tries the team again after a cool-down.
     if (rc != TTSX_ERR_STATE || d->plan_team == 1) return rc;
-    d->team_gave_up = true;
+    d->team_cool.start();
     rc = ttsx_t2_decoder_begin(d, enc, enc_len, B, T, stream);
     if (rc) return rc;
     TTSX_HIP(hipMemsetAsync(n_steps, 0, sizeof(int32_t) * B, st));
@@ -2754,6 +2765,14 @@ extern "C" int ttsx_t2_decoder_run(ttsx_t2_decoder* d, const float* enc, const i
   TTSX_HIP(hipMemcpyAsync(&sync_failed, &d->rc->sync_failed, sizeof(int), hipMemcpyDeviceToHost, st));
   TTSX_HIP(hipStreamSynchronize(st));
   if (sync_failed) {
+    // (workgroups of one launch that were not resident together.)  Under the default plan the handle stops fusing
+    // and the run starts over with prenet layer 2 as a launch of its own; state handed over by set_initial was
+    // consumed by the failed attempt, so such a run reports the error instead.
+    if (d->plan_fuse_p2 == -1 && !d->fuse_gave_up && !carried) {
+      d->fuse_gave_up = true;
+      return ttsx_t2_decoder_run(d, enc, enc_len, B, T, r, max_steps, stop_threshold, fixed_steps, mel, align, stop,
+                                 n_steps, steps_run_host, stream);
+    }
     ttsx_set_error("ttsx_t2_decoder_run: a prenet workgroup waited too long for the projection rows of its own launch");
     return TTSX_ERR_STATE;
   }

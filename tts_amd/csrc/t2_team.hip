@@ -45,7 +45,6 @@ constexpr int LOCF = 32, LOCK = 31, LPAD = 15, TMAX = 256;  // (attention roles 
 constexpr int N_ATT = 64, N_DEC = 128, N_PROJ = 16, N_EN = 4;  // (and as many context workgroups as energy workgroups)
 constexpr int G_DEC0 = N_ATT, G_PROJ0 = G_DEC0 + N_DEC, G_EN0 = G_PROJ0 + N_PROJ;
 constexpr unsigned DONE_BIT = 0x80000000u;
-constexpr long SPIN_LIMIT = 4000000;
 constexpr int PROJ_K = DD + ED;
 
 // register images: slot s of thread tid of workgroup g of a role at img[(g * NS + s) * NT + tid]
@@ -98,6 +97,7 @@ __device__ __forceinline__ void publish(u64* X, int idx, float v, unsigned tag) 
 template <int N>
 __device__ __forceinline__ int poll_span(const u64* X, int n, unsigned tag, float* dst, int* abort_word) {
   const int tid = threadIdx.x;
+  long long t_wait = 0;
   for (long spin = 0;; ++spin) {
     u64 v[N];
     bool ok = true, dn = false;
@@ -116,7 +116,7 @@ __device__ __forceinline__ int poll_span(const u64* X, int n, unsigned tag, floa
       return __any(dn) ? 2 : 0;
     }
     if ((spin & 127) == 127 && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return 1;
-    if (spin > SPIN_LIMIT) {
+    if (team_wait_expired(spin, t_wait)) {
       __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       return 1;
     }
@@ -140,6 +140,7 @@ __device__ __forceinline__ int fetch_span2(const u64* XA, int na, const u64* XB,
                                            int* abort_word, int* s_flag) {
   const int tid = threadIdx.x, n = na + nb;
   int st = -1;
+  long long t_wait = 0;
   for (long spin = 0; st < 0; ++spin) {
     u64 v[N];
     bool ok = true, dn = false;
@@ -158,7 +159,7 @@ __device__ __forceinline__ int fetch_span2(const u64* XA, int na, const u64* XB,
       st = __any(dn) ? 2 : 0;
     } else if ((spin & 127) == 127 && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
       st = 1;
-    } else if (spin > SPIN_LIMIT) {
+    } else if (team_wait_expired(spin, t_wait)) {
       __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       st = 1;
     } else {
