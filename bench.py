@@ -54,6 +54,35 @@ GL_BYTES_PER_FRAME = 61 * 1025 * 4 + 121 * 275 * 4   # 60 iterations: magnitudes
 GL_FLOPS_PER_FRAME = 121 * 2.5 * 2048 * 11           # 121 real FFTs of 2048 points
 
 
+# One exchange between the workgroups of a persistent team (every workgroup publishes its words with one store,
+# every consumer polls each word once): measured 1.5 - 1.9 us at the team sizes used (tools/exchange_probe.hip:
+# 1.15 us bare at 32 workgroups / 256 words, 1.9 us at 256 workgroups / 1024 words; in-kernel timestamps of the
+# team kernels: tools/t2_team_timing.py).  The serial chain of a decoder step holds six of them.
+TEAM_EXCHANGE_US = 1.7
+TEAM_EXCHANGES_T2 = 6
+TEAM_EXCHANGES_T1 = 6
+
+
+def team_bound(us_per_step, exchanges):
+    floor = exchanges * TEAM_EXCHANGE_US
+    return {"bound": "exchange latency", "exchanges_on_the_serial_chain": exchanges,
+            "exchange_us": TEAM_EXCHANGE_US, "floor_us": floor, "frac": floor / us_per_step}
+
+
+def team_traffic(case):
+    """HBM bytes per decoder step of a team kernel from the counter passes kept under profiles/ (a separate
+    rocprofv3 run: tools/profile_team.sh), or None."""
+    path = os.path.join(ROOT, "profiles", "r3_team_pmc.csv")
+    if not os.path.exists(path):
+        return None
+    import csv
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            if row["case"] == case and "team_kernel" in row["kernel"] and "pack" not in row["kernel"]:
+                return float(row["hbm_bytes_per_step"])
+    return None
+
+
 def dec_step_bytes(B, T):
     return DEC_WEIGHT_BYTES + 2580.0 * T * B
 
@@ -474,7 +503,7 @@ def main():
     # HBM bytes per step from the PMC passes kept under profiles/ (a separate rocprofv3 run on the same
     # workload; counters cannot be read from inside this process)
     roof["traffic"] = None
-    for name in ("r2_decoder_pmc.json", "r1_decoder_pmc.json"):
+    for name in ("r3_decoder_pmc.json", "r2_decoder_pmc.json", "r1_decoder_pmc.json"):
         pmc_path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(pmc_path):
             pmc = json.load(open(pmc_path))
@@ -533,15 +562,17 @@ def main():
         out["batch1"] = {"latency_s": lat, "audio_s": F_total * 275 / 22050.0,
                          "real_time_factor": lat / (F_total * 275 / 22050.0), "frames_per_s": F_total / lat,
                          "stage_ms": s1, "decoder_us_per_step": d_us,
-                         "decoder_hbm_gbs": dec_step_bytes(1, 100) / (d_us * 1e-6) / 1e9,
-                         "decoder_hbm_frac": dec_step_bytes(1, 100) / (d_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                         # the same against what a plain streaming read of an Infinity-Cache-resident 76 MB buffer
-                         # reaches on this part (tools/stream_probe.hip: 6.6 TB/s; from HBM 6.1 TB/s)
-                         "decoder_vs_measured_stream_frac": dec_step_bytes(1, 100) / (d_us * 1e-6) / 1e9 / 6600.0,
                          "workload": "B=1, T_in=100, %d decoder steps, r=%d" % (S, r),
-                         "decoder_path": "persistent team kernel: one launch per run, LSTM weights resident in "
-                                         "registers and LDS (decoder_hbm_* price the step at the launch chain's "
-                                         "algorithmic bytes; the weights do not move)"}
+                         "decoder_path": "persistent team kernel: one launch per run, every decoder weight resident "
+                                         "in registers and LDS; activations cross the chip as tagged words",
+                         # What bounds a step of the team kernel is not memory bandwidth (no weight byte moves) but
+                         # the six dependent exchanges on its serial chain (x1 | x2 | h_a | partial energies |
+                         # context | h_d), each one publish + poll round trip through the memory side.
+                         "decoder_bound": team_bound(d_us, TEAM_EXCHANGES_T2),
+                         # side note: the same step priced at the launch chain's algorithmic bytes (weights once per
+                         # step); the counters show that these bytes do not move
+                         "decoder_hbm_equivalent_gbs": dec_step_bytes(1, 100) / (d_us * 1e-6) / 1e9,
+                         "decoder_hbm_bytes_per_step_measured": team_traffic("t2_100_800")}
         # the same decode as a chain of launches (what batch 2 and up, and texts beyond 128 symbols, run)
         model.set_team(0)
         wlc = Workload(model, ap, ids1, S, ph1)
@@ -554,6 +585,8 @@ def main():
         import io
         with contextlib.redirect_stdout(io.StringIO()):   # the model reports 'max_decoder_steps' like the reference
             v1 = tacotron_v1_batch1(dev)
+        v1["decoder_bound"] = team_bound(v1["decoder_us_per_step"], TEAM_EXCHANGES_T1)
+        v1["decoder_hbm_bytes_per_step_measured"] = team_traffic("t1_100_200")
         out["tacotron_v1_batch1"] = v1
         # long-form input: ~1000 symbols, 2000 decoder steps (attention over a long encoder axis)
         idsL = torch.as_tensor(synthetic.t2_text_ids(77, 1, 1000)).to(dev)
@@ -568,7 +601,9 @@ def main():
         sL = wlL.stages()
         out["longform"] = {"workload": "B=1, T_in=1000, 2000 decoder steps, r=%d" % r, "latency_s": latL,
                            "real_time_factor": latL / (2000 * r * 275 / 22050.0), "stage_ms": sL,
-                           "decoder_us_per_step": sL["decoder"] * 1e3 / 2000}
+                           "decoder_us_per_step": sL["decoder"] * 1e3 / 2000,
+                           "decoder_bound": team_bound(sL["decoder"] * 1e3 / 2000, TEAM_EXCHANGES_T2),
+                           "decoder_hbm_bytes_per_step_measured": team_traffic("t2_1000_2000")}
         # the same decoder at the batch sizes the corpus workload runs: marginal time per step between a 200-step and
         # a 100-step run (set-up cancels), against the fp32-MFMA peak.  The step of the headline batch (64 columns) is
         # bound by its chain of dependent launches; wider batches amortise it.
