@@ -160,6 +160,14 @@ int ttsx_t2_decoder_run(ttsx_t2_decoder* dec, const float* enc, const int32_t* e
  * the shapes allow.  For A/B timing and for tests that hold the alternatives against each other. */
 int ttsx_t2_decoder_set_plan(ttsx_t2_decoder* dec, int fused_attention, int split_lstm, int share_query);
 
+/* Batches padded to 64 columns with the early / late LSTM split and the fused attention launch: how the early
+ * columns of the decoder LSTM, which run beside the attention, are tiled (no reference counterpart).  0: 32 x 32
+ * register tiles over two halves of K, two workgroups per CU; 1: 128 rows x 64 columns x one of six K parts per
+ * workgroup with the activation slice shared through LDS, every workgroup of the launch on a CU of its own (the
+ * attention workgroups no longer share theirs); -1 (default): staged wherever the shapes allow.  The step is the same
+ * (rounding differs at 1e-6: six partial sums instead of two). */
+int ttsx_t2_decoder_set_pieces(ttsx_t2_decoder* dec, int staged);
+
 /* Batches on the MFMA engine (B > 2): prenet layer 2 of a step inside the projection launch of the step before it
  * (its workgroups wait for flags that the projection's row blocks raise: one launch boundary less per step).
  * No reference counterpart.  -1 where it measured faster (padded batch 64 with the early / late LSTM split), 0 never,

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Run only the Tacotron2 decoder loop (for kernel profiles and step timing): dec_only.py B T steps [fused split share [team [fusion]]]
+"""Run only the Tacotron2 decoder loop (for kernel profiles and step timing): dec_only.py B T steps [fused split share [team [fusion [pieces]]]]
 (the optional launch-plan overrides of Tacotron2.set_plan / set_team: -1 by shape, 0 off, 1 on).
 Prints the marginal time per step (difference between a run of `steps` and one of `steps`/2 steps,
 so that per-run set-up cancels) and the all-in figure."""
@@ -21,6 +21,8 @@ if len(sys.argv) > 7:
     model.set_team(int(sys.argv[7]))
 if len(sys.argv) > 8:
     model.set_fusion(int(sys.argv[8]))
+if len(sys.argv) > 9:
+    model.set_pieces(int(sys.argv[9]))
 ids = torch.as_tensor(synthetic.t2_text_ids(5, B, T)).cuda()
 enc = model.encode(ids)
 

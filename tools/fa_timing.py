@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Phase timestamps of the fused attention kernel (tuning build: make the library with -DTTSX_FA_TIMING
-as tts_amd/libttsx_dbg.so and run with TTSX_LIB=libttsx_dbg.so): fa_timing.py B T"""
+as tts_amd/libttsx_dbg.so and run with TTSX_LIB=libttsx_dbg.so): fa_timing.py B T [pieces [split]]"""
 import ctypes
 import os
 import sys
@@ -13,6 +13,10 @@ from tts_amd import _lib, synthetic  # noqa: E402
 
 B, T = int(sys.argv[1]), int(sys.argv[2])
 model, ap, sd = bench.build_model(0, 1)
+if len(sys.argv) > 3:
+    model.set_pieces(int(sys.argv[3]))
+if len(sys.argv) > 4:
+    model.set_plan(-1, int(sys.argv[4]), -1)
 ids = torch.as_tensor(synthetic.t2_text_ids(5, B, T)).cuda()
 enc = model.encode(ids)
 model.decode(enc, None, fixed_steps=64)

@@ -138,6 +138,108 @@ __global__ __launch_bounds__(THREADS) void part_kernel(const float* __restrict__
   MARK(6);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// STAGED, one round: 256 workgroups, workgroup = (row group of 8 row blocks = 128 rows, one wave each) x (one K part
+// of KGP k-groups) x all 64 columns.  The activation slice of the part (KGP * 16 x 64 floats) goes through LDS and is
+// shared by the eight waves; every wave streams the weights of its own row block into registers and owns its rows
+// for the whole part, so there is no combine across waves.  Request order: every wave's slice loads, a barrier
+// (issue only - nothing is waited for), then the weights: the slice - L2 hits - never queues behind weight misses of
+// another wave of the CU.  The slice lands in chunks of CH k-groups; matrix instructions of chunk c start when it
+// is in LDS.
+// MODE 0: as described; 1: no barrier between slice and weight requests; 2: no matrix instructions; 3: no weights
+template <int KGP, int CH, int MODE>
+__global__ __launch_bounds__(THREADS) void staged_kernel(const float* __restrict__ Wp, int kg_stride,
+                                                         const float* __restrict__ X, float* __restrict__ gates,
+                                                         int gates_part_stride, int nrg) {
+  extern __shared__ float4 part_lds[];
+  MARK(0);
+  constexpr int NJ = KGP / 2;  // slice loads per thread: 512 float4 = two k-groups each
+  const int wg = blockIdx.x, tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int part = wg / nrg, rb = (wg % nrg) * 8 + wave;
+  const float4* Xs = reinterpret_cast<const float4*>(X) + (size_t)part * KGP * 256 + tid;
+  float4 xr[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) xr[j] = Xs[j * THREADS];
+  if (MODE != 1) asm volatile("s_barrier" ::: "memory");
+  const float4* W = reinterpret_cast<const float4*>(Wp) + ((size_t)rb * kg_stride + part * KGP) * 64 + lane;
+  float4 wv[KGP];
+#pragma unroll
+  for (int i = 0; i < KGP; ++i) wv[i] = MODE == 3 ? make_float4(1.f, 2.f, 3.f, lane) : W[(size_t)i * 64];
+  f32x4 acc[4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const float4* xl = part_lds + (lane >> 4) * 64 + (lane & 15);
+#pragma unroll
+  for (int c = 0; c < KGP / CH; ++c) {
+#pragma unroll
+    for (int jj = 0; jj < CH / 2; ++jj) part_lds[tid + (c * (CH / 2) + jj) * THREADS] = xr[c * (CH / 2) + jj];
+    lds_barrier();
+    if (c == 0) MARK(1);
+#pragma unroll
+    for (int ii = 0; ii < CH; ++ii) {
+      const int i = c * CH + ii;
+      float4 xv[4];
+#pragma unroll
+      for (int n = 0; n < 4; ++n) xv[n] = xl[i * 256 + n * 16];
+#define SLS(C)                                                                                   \
+  _Pragma("unroll") for (int n = 0; n < 4; ++n) {                                                \
+    if (MODE == 2) acc[n][0] += wv[i].C * xv[n].C;                                               \
+    else acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[i].C, xv[n].C, acc[n], 0, 0, 0);       \
+  }
+      SLS(x) SLS(y) SLS(z) SLS(w)
+#undef SLS
+    }
+    if (c == 0) MARK(2);
+  }
+  MARK(3);
+  float4* O = reinterpret_cast<float4*>(gates) + (size_t)part * gates_part_stride + (size_t)(rb * 4 + (lane >> 4)) * PART_COLS +
+              (lane & 15);
+#pragma unroll
+  for (int n = 0; n < 4; ++n) O[n * 16] = make_float4(acc[n][0], acc[n][1], acc[n][2], acc[n][3]);
+  MARK(4);
+}
+
+template <int KGP, int CH, int MODE>
+void run_staged(const char* what, const float* dW, const float* dX, float* dO, int K, const std::vector<float>& hW,
+                const std::vector<float>& hX, bool check) {
+  const int KG = K / 16, nparts = KG / KGP, nrg = ROWS / 128;
+  const size_t nO = (size_t)nparts * ROWS * BPAD;
+  const int smem = KGP * 256 * 16;
+  hipFuncSetAttribute(reinterpret_cast<const void*>(staged_kernel<KGP, CH, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+  hipEvent_t a, b;
+  hipEventCreate(&a), hipEventCreate(&b);
+  const int grid = nrg * nparts;
+  float ms = 0;
+  for (int rep = 0; rep < 2; ++rep) {
+    hipEventRecord(a);
+    for (int i = 0; i < 200; ++i)
+      staged_kernel<KGP, CH, MODE><<<grid, THREADS, smem>>>(dW, KG, dX, dO, ROWS / 4 * BPAD, nrg);
+    hipEventRecord(b);
+    hipEventSynchronize(b);
+    hipEventElapsedTime(&ms, a, b);
+  }
+  long long m[2][8];
+  hipMemcpyFromSymbol(m, HIP_SYMBOL(g_marks), sizeof(m));
+  printf("%-44s grid %4d  %.2f us per launch (%.1f TFLOP/s)\n", what, grid, ms * 5.f, 2.0 * ROWS * K * BPAD / (ms * 5e-6) / 1e12);
+  for (int w = 0; w < 2; ++w)
+    printf("   %s workgroup: first chunk in LDS %.2f us, its MFMAs %.2f, remaining chunks %.2f, store %.2f | total %.2f\n",
+           w ? "last " : "first", (m[w][1] - m[w][0]) / 100.0, (m[w][2] - m[w][1]) / 100.0, (m[w][3] - m[w][2]) / 100.0,
+           (m[w][4] - m[w][3]) / 100.0, (m[w][4] - m[w][0]) / 100.0);
+  if (!check) return;
+  std::vector<float> hO(nO);
+  hipMemcpy(hO.data(), dO, nO * 4, hipMemcpyDeviceToHost);
+  double worst = 0;
+  for (int r : {0, 17, 130, 4095})
+    for (int c : {0, 33, 63}) {
+      double ref = 0, got = 0;
+      for (int k = 0; k < K; ++k) ref += (double)hW[(size_t)r * K + k] * hX[(size_t)k * BPAD + c];
+      for (int p = 0; p < nparts; ++p) got += hO[(size_t)p * ROWS * BPAD + ((size_t)(r >> 2) * BPAD + c) * 4 + (r & 3)];
+      worst = fmax(worst, fabs(ref - got));
+    }
+  printf("   max |err| %.3e\n", worst);
+}
+
 template <int VARIANT>
 void run(const char* what, const float* dW, const float* dX, float* dO, int K, const std::vector<float>& hW,
          const std::vector<float>& hX, bool check) {
@@ -203,5 +305,13 @@ int main() {
   run<1>("no matrix instructions", dW, dX, dO, K, hW, hX, false);
   run<2>("no weight loads", dW, dX, dO, K, hW, hX, false);
   run<3>("slice first, then weights", dW, dX, dO, K, hW, hX, true);
+  hipMemset(dO, 0, nO * 4);
+  run_staged<16, 4, 0>("staged one round 128x64x256, chunks of 4", dW, dX, dO, K, hW, hX, true);
+  run_staged<16, 4, 1>("  no barrier between slice and weights", dW, dX, dO, K, hW, hX, false);
+  run_staged<16, 4, 2>("  no matrix instructions", dW, dX, dO, K, hW, hX, false);
+  run_staged<16, 4, 3>("  no weight loads", dW, dX, dO, K, hW, hX, false);
+  run_staged<16, 2, 0>("staged, chunks of 2", dW, dX, dO, K, hW, hX, true);
+  run_staged<16, 8, 0>("staged, chunks of 8", dW, dX, dO, K, hW, hX, true);
+  run_staged<8, 4, 0>("staged 128x64x128 (512 workgroups)", dW, dX, dO, K, hW, hX, true);
   return 0;
 }

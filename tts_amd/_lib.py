@@ -101,6 +101,7 @@ PROTOTYPES = {
     "ttsx_t2_decoder_set_plan": (c_int, [c_void_p, c_int, c_int, c_int]),
     "ttsx_t2_decoder_set_team": (c_int, [c_void_p, c_int]),
     "ttsx_t2_decoder_set_fusion": (c_int, [c_void_p, c_int]),
+    "ttsx_t2_decoder_set_pieces": (c_int, [c_void_p, c_int]),
     "ttsx_t2_decoder_set_polling": (c_int, [c_void_p, c_int, c_int]),
     "ttsx_t2_decoder_begin": (c_int, [c_void_p, _fp, _fp, c_int, c_int, c_void_p]),
     "ttsx_t2_decoder_load_state": (c_int, [c_void_p] + [_fp] * 7 + [c_void_p]),

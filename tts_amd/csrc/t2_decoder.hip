@@ -196,8 +196,23 @@ __global__ void compose_proj_ext_kernel(float* __restrict__ ext_w, float* __rest
 // phase timestamps of workgroup 0 (100 MHz wall clock), for tuning builds only
 __device__ long long g_fa_t[16];
 #define FA_MARK(i) do { if (wg == 0 && threadIdx.x == 0) g_fa_t[i] = wall_clock64(); } while (0)
+// start, end and placement of every workgroup of the launches whose grid size equals g_wg_grid (each such launch
+// overwrites the one before): [start, end, HW_ID register, XCC_ID register]
+__device__ long long g_wg_t[2048][4];
+__device__ int g_wg_grid, g_wg_first;
+__device__ __forceinline__ void wg_mark(long long t0, int n_first) {
+  if (threadIdx.x == 0 && (int)gridDim.x == g_wg_grid && n_first == g_wg_first && gridDim.x <= 2048) {
+    long long* r = g_wg_t[blockIdx.x];
+    r[0] = t0, r[1] = wall_clock64();
+    r[2] = __builtin_amdgcn_s_getreg((31 << 11) | 4), r[3] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+  }
+}
+#define WG_T0() const long long wg_t0 = wall_clock64()
+#define WG_MARK(n) wg_mark(wg_t0, n)
 #else
 #define FA_MARK(i) do { } while (0)
+#define WG_T0() do { } while (0)
+#define WG_MARK(n) do { } while (0)
 #endif
 
 // ------------------------------------------------------------------ GEMM / GEMV engines
@@ -259,6 +274,9 @@ struct GemmP {
   int step_in_chunk;
 };
 
+// K parts of the decoder LSTM's early columns when its pieces stage their activations in LDS (StagedPieceOp)
+constexpr int STAGED_PARTS = 6;
+
 // Operands of the epilogue of one (quad, utterance) pair, fetched while the weights stream.
 struct Pre {
   float4 bias, gates;
@@ -275,7 +293,15 @@ __device__ __forceinline__ Pre prefetch_quad(const GemmP& p, int quad, int b) {
     if (p.gates) {
       const float4* G = reinterpret_cast<const float4*>(p.gates) + (size_t)quad * gp + p.gates_col0 + b;
       r.gates = G[0];
-      if (p.kparts > 1) {
+      if (p.kparts == STAGED_PARTS) {
+        // (all requested before the first sum; added in part order)
+        float4 gk[STAGED_PARTS - 1];
+#pragma unroll
+        for (int k = 1; k < STAGED_PARTS; ++k) gk[k - 1] = G[(size_t)k * p.gates_part_stride];
+#pragma unroll
+        for (int k = 0; k < STAGED_PARTS - 1; ++k)
+          r.gates.x += gk[k].x, r.gates.y += gk[k].y, r.gates.z += gk[k].z, r.gates.w += gk[k].w;
+      } else if (p.kparts > 1) {
         const float4 g2 = G[p.gates_part_stride];
         r.gates.x += g2.x, r.gates.y += g2.y, r.gates.z += g2.z, r.gates.w += g2.w;
       }
@@ -526,13 +552,13 @@ struct GemmOp {
       if (MODE == MODE_LSTM || MODE == MODE_GRU) s_h[(t / NT) * 4 + (lane >> 4)][(t % NT) * 16 + (lane & 15)] = h;
     }
     if (KGW == 20) FA_MARK(11);
-    if (MODE == MODE_PROJ && R == 1 && NT == 1 && p.x1_flags) {
-      // (one tile per workgroup: wave 0 alone has written it) the stores have reached memory, then the flag
+    if (MODE == MODE_PROJ && R == 1 && NT <= GEMM_WAVES && p.x1_flags) {
+      // (one row block: wave t alone has written column tile t) the stores have reached memory, then the flag
       const int xb = rb - (p.o_quads / 4 + 1);
-      if (xb >= 0 && wave == 0) {
+      if (xb >= 0 && wave < NT) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0)
-          __hip_atomic_store(p.x1_flags + (b0 / 16) * (PRENET_DIM / 16) + xb,
+          __hip_atomic_store(p.x1_flags + (b0 / 16 + wave) * (PRENET_DIM / 16) + xb,
                              (unsigned)(p.ctx->base + p.step_in_chunk + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
@@ -548,6 +574,98 @@ struct GemmOp {
         dst[(size_t)c * ATT_DIM] = acc;
       }
     }
+  }
+};
+
+// An LDS-only barrier: __syncthreads() carries a fence that waits for every outstanding global load, which would
+// serialise loads that were issued early on purpose.
+__device__ __forceinline__ void lds_only_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Piece of early LSTM columns at padded batch 64 with the activations staged in LDS (MODE_PARTIAL only): a workgroup
+// is (8 row blocks = 128 gate rows, one wave each) x (one of PARTS parts of K) x all 64 columns.  The part's
+// activation slice (contiguous in the quad layout) is read once per workgroup and shared by its eight waves through
+// LDS; every wave streams the weights of its own row block into registers and owns its rows over the whole part, so
+// nothing is combined across waves, and once its operands arrive a workgroup keeps the matrix pipes of its CU
+// full.  That is also why such a workgroup must not share a CU with a workgroup of the serial path (measured: the
+// fused attention workgroup of an utterance takes 21 us instead of 11 next to one - its own matrix instructions
+// and its loads queue behind the piece's): the launch asks for more than half a CU's LDS per workgroup (the slice
+// of the longest part is 88 KB), so every workgroup gets a CU of its own, and the K range is cut into as many parts
+// as leave one workgroup per remaining CU (decoder LSTM: 128 k-groups in 6 parts = 192 workgroups beside the 64
+// attention workgroups).  Parts hold an even number of k-groups: KB, or KB + 2 for the first NX parts.
+// Request order: every wave's share of the slice, a barrier (issue only, nothing is waited for), then weights, eight
+// k-groups ahead of their use; the slice lands in chunks of four k-groups and the matrix instructions of a chunk
+// start when it is in LDS.  Part k goes to gates + k * gates_part_stride; the late LSTM launch adds the parts.
+template <int KG_TOTAL, int PARTS>
+struct StagedPieceOp {
+  typedef GemmP P;
+  static constexpr int KB = (KG_TOTAL / PARTS) & ~1, NX = (KG_TOTAL - PARTS * KB) / 2, KMAX = NX ? KB + 2 : KB;
+  static constexpr int CH = 4, WD = 8, NJ = KMAX / 2;
+  static constexpr int LDS_BYTES = KMAX * 256 * (int)sizeof(float4);
+  static_assert(KB % CH == 0 && KB >= WD && NX <= PARTS && KB * PARTS + 2 * NX == KG_TOTAL, "parts of K");
+  static __device__ __forceinline__ void run(const GemmP& p, int wg) {
+    // (native vector types: copies of the float4 struct between memory spaces compile to block copies through a
+    // per-lane array, not to registers)
+    extern __shared__ f32x4 staged_lds[];
+    const int done = step_done(p.ctx, p.step_in_chunk);
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int nrg = p.nrb / GEMM_WAVES;
+    const int part = p.kpart0 + wg / nrg, rb = p.rb0 + (wg % nrg) * GEMM_WAVES + wave;
+    const int kg_first = part * KB + 2 * min(part, NX);
+    const bool tail = part < NX;  // this part has KB + 2 k-groups
+    // the slice: thread tid owns float4 tid of every pair of k-groups (a k-group is 4 quads x 64 columns)
+    const f32x4* X0 = reinterpret_cast<const f32x4*>(seg_ptr(p.seg[0], p.parity)) + tid;
+    const f32x4* X1 = p.nseg > 1 ? reinterpret_cast<const f32x4*>(seg_ptr(p.seg[1], p.parity)) + tid : X0;
+    const int e0 = p.seg[0].kgroups;
+    f32x4 xr[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      // (segments and parts hold an even number of k-groups; a part without the last pair reads its own last pair
+      // again - a load inside a branch would wait for its own round trip)
+      const int g = kg_first + 2 * ((j < KB / 2 || tail) ? j : KB / 2 - 1);
+      xr[j] = g < e0 ? X0[(size_t)g * 256] : X1[(size_t)(g - e0) * 256];
+    }
+    asm volatile("s_barrier" ::: "memory");
+    const f32x4* W = reinterpret_cast<const f32x4*>(p.Wp) + ((size_t)rb * p.kg_stride + p.kg0 + kg_first) * 64 + lane;
+    const int last = tail ? KMAX - 1 : KB - 1;
+    f32x4 wv[KMAX];
+#pragma unroll
+    for (int i = 0; i < WD; ++i) wv[i] = W[(size_t)i * 64];
+    f32x4 acc[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const f32x4* xl = staged_lds + (lane >> 4) * 64 + (lane & 15);
+#define TTSX_SLICE(C) \
+  _Pragma("unroll") for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[i].C, xv[n].C, acc[n], 0, 0, 0);
+#define TTSX_KGROUP(i_)                                                          \
+  {                                                                              \
+    const int i = (i_);                                                          \
+    f32x4 xv[4];                                                                 \
+    _Pragma("unroll") for (int n = 0; n < 4; ++n) xv[n] = xl[i * 256 + n * 16];   \
+    TTSX_SLICE(x) TTSX_SLICE(y) TTSX_SLICE(z) TTSX_SLICE(w)                      \
+  }
+#pragma unroll
+    for (int c = 0; c < KB / CH; ++c) {
+#pragma unroll
+      for (int jj = 0; jj < CH / 2; ++jj) staged_lds[tid + (c * (CH / 2) + jj) * GEMM_THREADS] = xr[c * (CH / 2) + jj];
+      if (c == KB / CH - 1 && NX) staged_lds[tid + (KB / 2) * GEMM_THREADS] = xr[KB / 2];  // (the last pair rides along)
+      lds_only_barrier();
+#pragma unroll
+      for (int ii = 0; ii < CH; ++ii) TTSX_KGROUP(c * CH + ii)
+#pragma unroll
+      for (int ii = 0; ii < CH; ++ii)
+        if (c * CH + WD + ii < KMAX) wv[c * CH + WD + ii] = W[(size_t)min(c * CH + WD + ii, last) * 64];
+    }
+    if (NX && tail) {
+      TTSX_KGROUP(KB)
+      TTSX_KGROUP(KB + 1)
+    }
+#undef TTSX_KGROUP
+#undef TTSX_SLICE
+    if (done) return;
+    float4* O = reinterpret_cast<float4*>(p.gates) + (size_t)part * p.gates_part_stride +
+                (size_t)(rb * 4 + (lane >> 4)) * p.Bpad + (lane & 15);
+#pragma unroll
+    for (int n = 0; n < 4; ++n) O[n * 16] = make_float4(acc[n][0], acc[n][1], acc[n][2], acc[n][3]);
   }
 };
 
@@ -659,8 +777,10 @@ struct NoOp {
 // rest run op B (a piece of partial LSTM work).
 template <class A, class B>
 __global__ __launch_bounds__(GEMM_THREADS) void dual_kernel(typename A::P pa, typename B::P pb, int n_first) {
+  WG_T0();
   if ((int)blockIdx.x < n_first) A::run(pa, blockIdx.x);
   else B::run(pb, blockIdx.x - n_first);
+  WG_MARK(n_first);
 }
 
 // Prenet layer 2 of the NEXT step inside the projection launch of this one (MFMA engine): one launch boundary
@@ -747,10 +867,12 @@ __global__ __launch_bounds__(GEMM_THREADS) void triple_kernel(typename A::P pa, 
 template <class A, class C, class B>
 __global__ __launch_bounds__(GEMM_THREADS) void triple_kernel_b_first(typename A::P pa, typename C::P pc, typename B::P pb,
                                                                       int na, int nb) {
+  WG_T0();
   const int wg = blockIdx.x;
   if (wg < na) A::run(pa, wg);
   else if (wg < na + nb) B::run(pb, wg - na);
   else C::run(pc, wg - na - nb);
+  WG_MARK(na);
 }
 
 // ------------------------------------------------------------------ attention
@@ -1297,6 +1419,9 @@ struct FusedAttnOp {
     float* s_al = s_e + FA_TMAX;               // [FA_TMAX]
     __shared__ float s_red[CTX_THREADS / 64];
     FA_MARK(0);
+    // This workgroup is on the step's serial path and shares its CU with a piece workgroup that keeps the matrix
+    // pipe full: its waves go first wherever both have an instruction ready.
+    __builtin_amdgcn_s_setprio(3);
 
     // ---- loads.  Vector loads return in order, so what the first barrier needs is requested first
     // (query shares, weight fragments, alignment rows) and the encoder rows of the context - 128 KB
@@ -1669,6 +1794,8 @@ struct ttsx_t2_decoder {
   int32_t* len_ws;   // [B] encoder lengths (T where the caller gave none)
   int parity0;       // decoder steps completed before the launches being enqueued, & 1
   bool split;        // LSTMs cut into early/late columns with the early part riding along other launches
+  bool staged;       // (MFMA engine, padded batch 64) the early-column pieces stage their activations in LDS
+  int plan_staged;   // ttsx_t2_decoder_set_pieces: -1 by shape (default), 0 register tiles, 1 staged where possible
   float *g_a, *g_d;  // raw gate sums of the partial LSTM launches, quad layout [4096/4][Bpad] float4
   RunCtx* rc;        // device
   RunCtx* rc_host;   // pinned staging copy
@@ -1800,7 +1927,7 @@ int ensure_workspace(ttsx_t2_decoder* d, int B, int T) {
     rc |= dev_alloc(&d->c_a, QUERY_DIM * cb);
     rc |= dev_alloc(&d->c_d, DEC_DIM * cb);
     rc |= dev_alloc(&d->g_a, 2 * 4 * QUERY_DIM * cb);  // two K parts
-    rc |= dev_alloc(&d->g_d, 2 * 4 * DEC_DIM * cb);
+    rc |= dev_alloc(&d->g_d, STAGED_PARTS * 4 * DEC_DIM * cb);  // two K parts, or those of the staged pieces
     rc |= dev_alloc(&d->q, ATT_DIM * cb);
     rc |= dev_alloc(&d->o, (size_t)round_up(proj_rows(d->r_init), 16) * cb);
     rc |= dev_alloc(&d->len_ws, cb);
@@ -1890,6 +2017,22 @@ struct piece_in_dyn_lds<FusedAttnOp<NTT, EDIM, PRE>> {
   static constexpr bool value = true;
 };
 
+// Ops that share a launch with staged pieces (the fused attention; none)
+template <class A>
+struct staged_partner {
+  static constexpr bool value = false;
+};
+template <>
+struct staged_partner<NoOp> {
+  static constexpr bool value = true;
+};
+template <int NTT, int EDIM, int PRE>
+struct staged_partner<FusedAttnOp<NTT, EDIM, PRE>> {
+  static constexpr bool value = true;
+};
+// What a launch with staged pieces asks for per workgroup: more than half the LDS of a CU
+constexpr size_t STAGED_LDS_MIN = 84 * 1024;
+
 template <class A, int PK>
 int launch_with_piece(const ttsx_t2_decoder* d, const typename A::P& pa, int na, size_t smem, const Piece* pc,
                       hipStream_t st) {
@@ -1908,6 +2051,24 @@ int launch_with_piece(const ttsx_t2_decoder* d, const typename A::P& pa, int na,
       const int nb = pc->g.nrb;
       if (d->B == 1) dual_kernel<A, GemvOp<1, PK, MODE_PARTIAL>><<<na + nb, GEMM_THREADS, smem, st>>>(pa, pc->g, na);
       else dual_kernel<A, GemvOp<2, PK, MODE_PARTIAL>><<<na + nb, GEMM_THREADS, smem, st>>>(pa, pc->g, na);
+    }
+  } else if (d->staged && pc->g.kparts == STAGED_PARTS) {
+    // 128 rows x 64 columns x one of STAGED_PARTS parts of K per workgroup, the activation slice through LDS, one
+    // workgroup per CU (the LDS request is what keeps a second one off it)
+    if constexpr (!staged_partner<A>::value || PK != (QUERY_DIM + DEC_DIM) / 16 / GEMM_WAVES) {
+      ttsx_set_error("launch_with_piece: no staged piece beside this op");
+      return TTSX_ERR_STATE;
+    } else {
+      typedef StagedPieceOp<PK * GEMM_WAVES, STAGED_PARTS> Op;
+      const int nb = pc->g.nrb / GEMM_WAVES * pc->nk;
+      const size_t lds = std::max(std::max(smem, (size_t)Op::LDS_BYTES), STAGED_LDS_MIN);
+      static bool raised = false;   // (per instantiation)
+      if (!raised) {
+        TTSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dual_kernel<A, Op>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        raised = true;
+      }
+      dual_kernel<A, Op><<<na + nb, GEMM_THREADS, lds, st>>>(pa, pc->g, na);
     }
   } else {
     // K in two parts of PK/2 k-groups per wave, 32 x 32 tiles (16 x 16 when the batch is one column tile)
@@ -2055,7 +2216,7 @@ Partial partial_dec(const ttsx_t2_decoder* d, int i) {
   g.Bpad = d->Bpad, g.ctx = d->rc, g.step_in_chunk = i, g.parity = (d->parity0 + i) & 1;
   g.Wp = d->w_lstm2, g.nseg = 2, g.KG = (QUERY_DIM + DEC_DIM) / 16, g.kg0 = ENC_DIM / 16, g.kg_stride = KG2;
   g.gates = d->g_d;
-  g.kparts = (d->B > GEMV_MAX_B || d->fused) ? 2 : 1, g.gates_part_stride = DEC_DIM * d->Bpad;
+  g.kparts = d->staged ? STAGED_PARTS : (d->B > GEMV_MAX_B || d->fused) ? 2 : 1, g.gates_part_stride = DEC_DIM * d->Bpad;
   g.seg[0] = Seg{{d->h_a[0], d->h_a[1]}, 2, QUERY_DIM / 16};
   g.seg[1] = Seg{{d->h_d[0], d->h_d[1]}, 1, DEC_DIM / 16};
   return Partial{g, DEC_DIM / 4};
@@ -2085,7 +2246,8 @@ int enqueue_step(ttsx_t2_decoder* d, int i, bool first, bool more, hipStream_t s
   // all rows, one K part (MFMA engine)
   auto k_piece = [](const Partial& pt, int kpart) {
     Piece q{pt.g, true};
-    q.g.rb0 = 0, q.g.nrb = pt.total_rb, q.g.kpart0 = kpart, q.nk = 1;
+    const int per = pt.g.kparts / 2;  // (one half of K: one part, or four staged parts)
+    q.g.rb0 = 0, q.g.nrb = pt.total_rb, q.g.kpart0 = kpart * per, q.nk = per;
     return q;
   };
   // prenet layer 2: x2 = relu(A2f x1 + b2f)   (+ last third of this step's attention partial)
@@ -2261,7 +2423,7 @@ int push_ctx(ttsx_t2_decoder* d, hipStream_t st) {
 int launch_chunk(ttsx_t2_decoder* d, int n, int chunk, hipStream_t st) {
   if (n == chunk) {
     ttsx_t2_decoder::ChunkGraph& g = d->graphs[chunk == CHUNK ? 0 : 1];   // (the cache key includes the chunk size)
-    const int split = (int)d->split + 2 * (int)d->share_q + 4 * (d->plan_fuse_p2 + 1) + 16 * (int)d->fuse_gave_up;
+    const int split = (int)d->split + 2 * (int)d->share_q + 4 * (d->plan_fuse_p2 + 1) + 16 * (int)d->fuse_gave_up + 32 * (int)d->staged;
     const bool cached = g.exec && g.B == d->B && g.T == d->T && g.r == d->rc_host->r && g.gen == d->ws_gen &&
                         g.chunk == n && g.split == split && g.fused == (int)d->fused;
     if (!cached) {
@@ -2328,7 +2490,7 @@ extern "C" int ttsx_t2_decoder_create(const ttsx_t2_decoder_weights* w, int r_in
   ScopeExit on_fail([&] { (void)ttsx_t2_decoder_destroy(d); });
   ScopeExit free_tmp([&] { (void)hipFree(w_ih2), (void)hipFree(a2f), (void)hipFree(b2f); });
   d->r_init = r_init, d->norm = attn_norm, d->odim = MEL_DIM * r_init;
-  d->plan_fused = d->plan_split = d->plan_share_q = d->plan_team = d->plan_fuse_p2 = -1;
+  d->plan_fused = d->plan_split = d->plan_share_q = d->plan_team = d->plan_fuse_p2 = d->plan_staged = -1;
   int rc = 0;
   rc |= pack_layer(&d->w_lstm1, &d->b_lstm1, w->attn_rnn_w_ih, PRENET_DIM + ENC_DIM, w->attn_rnn_w_hh, QUERY_DIM,
                    w->attn_rnn_b_ih, w->attn_rnn_b_hh, 4 * QUERY_DIM, QUERY_DIM, st);
@@ -2530,8 +2692,15 @@ extern "C" int ttsx_t2_decoder_begin(ttsx_t2_decoder* d, const float* enc, const
     // pays while the pieces fit into that shadow.  Measured per step, split / whole LSTM launches (T=128 unless
     // noted): B=4 34.1 / 37.2 us, B=16 33.7 / 37.4, B=32 38.2 / 41.0, B=32 T=256 45.2 / 48.8, B=64 T=64 48.1 / 47.6,
     // B=64 48.1 / 49.1, B=64 T=200 50.4 / 56.7, B=96 75.0 / 73.6.
-    const bool pays = d->Bpad <= 32 || (d->Bpad == 64 && T > 64) || d->plan_split == 1;
+    // Staged pieces for the decoder LSTM's early columns (StagedPieceOp): 64 columns exactly (the slice of a K
+    // part is then one contiguous block of the quad layout).  Measured per step, staged / 32 x 32 register tiles:
+    // B=64 T=128 45.3 / 46.5 us, B=48 45.3 / 46.3, B=64 T=64 45.3 (49.1 without the split), B=64 T=200 50.8 / 49.8
+    // (beyond 128 positions the attention workgroup is the longer one either way) -> up to 128 positions.
+    const bool can_stage = B > GEMV_MAX_B && d->Bpad == 64 && d->fused &&
+                           (d->plan_staged == 1 || (d->plan_staged == -1 && T <= 128));
+    const bool pays = d->Bpad <= 32 || (d->Bpad == 64 && (T > 64 || can_stage)) || d->plan_split == 1;
     d->split = (B <= GEMV_MAX_B || (d->fused && pays)) && d->plan_split != 0 && !d->variant && !graves;
+    d->staged = can_stage && d->split;
   }
   d->parity0 = 0;
   const size_t cb = d->Bpad;
@@ -2802,6 +2971,13 @@ extern "C" int ttsx_t2_decoder_set_fusion(ttsx_t2_decoder* d, int prenet_in_proj
   return TTSX_OK;
 }
 
+extern "C" int ttsx_t2_decoder_set_pieces(ttsx_t2_decoder* d, int staged) {
+  TTSX_ARG(d, "ttsx_t2_decoder_set_pieces: null handle");
+  TTSX_ARG(staged >= -1 && staged <= 1, "ttsx_t2_decoder_set_pieces: the argument is -1 (by shape), 0 or 1");
+  d->plan_staged = staged;
+  return TTSX_OK;
+}
+
 extern "C" int ttsx_t2_decoder_set_team(ttsx_t2_decoder* d, int team) {
   TTSX_ARG(d, "ttsx_t2_decoder_set_team: null handle");
   TTSX_ARG(team >= -1 && team <= 1, "ttsx_t2_decoder_set_team: %d is not -1 (by shape), 0 (never) or 1 (wherever possible)", team);
@@ -3035,6 +3211,15 @@ extern "C" int ttsx_add_speaker_embedding(float* enc, const float* table, const 
 #ifdef TTSX_FA_TIMING
 extern "C" int ttsx_debug_fa_timing(long long* out_host) {
   TTSX_HIP(hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_fa_t), sizeof(long long) * 16));
+  return TTSX_OK;
+}
+// grid > 0: record the workgroups of launches with that grid size and that many serial-path workgroups from now on; out_host: [2048][4] of the last one
+extern "C" int ttsx_debug_wg_marks(int grid, int n_first, long long* out_host) {
+  if (grid > 0) {
+    TTSX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_wg_grid), &grid, sizeof(int)));
+    TTSX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_wg_first), &n_first, sizeof(int)));
+  }
+  if (out_host) TTSX_HIP(hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_wg_t), sizeof(long long) * 2048 * 4));
   return TTSX_OK;
 }
 #endif

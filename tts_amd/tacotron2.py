@@ -333,6 +333,11 @@ class Tacotron2:
         _lib.check(_lib.load().ttsx_t2_decoder_set_fusion(self._dec_handle, int(prenet_in_projection)),
                    "ttsx_t2_decoder_set_fusion")
 
+    def set_pieces(self, staged=-1):
+        """Padded batch 64: early-column pieces as 32 x 32 register tiles (0) or staged through LDS (1)
+        (ttsx_t2_decoder_set_pieces); -1 by shape."""
+        _lib.check(_lib.load().ttsx_t2_decoder_set_pieces(self._dec_handle, int(staged)), "ttsx_t2_decoder_set_pieces")
+
     def set_team(self, team=-1):
         """Whether batch-1 runs may use the persistent team kernel (ttsx_t2_decoder_set_team): -1 by shape, 0 never,
         1 wherever the shapes allow."""
