@@ -436,6 +436,8 @@ struct GemmOp {
   static __device__ __forceinline__ void run(const GemmP& p, int wg_in) {
     int wg = wg_in;
     if (KGW == 20) FA_MARK(8);
+    // (the projection is on the step's serial path and shares its CUs with piece workgroups: its waves go first)
+    if (MODE == MODE_PROJ) __builtin_amdgcn_s_setprio(3);
     const int done = step_done(p.ctx, p.step_in_chunk);
     const int ngrp = p.nrb / R;  // row-block groups of this launch
     int kpart = 0;
@@ -793,6 +795,7 @@ struct Prenet2AfterProjOp {
   typedef GemmP P;  // Wp / bias: prenet layer 2; seg[0].x[0]: x1; out[0]: x2; x1_flags; ctx, step_in_chunk of THIS step
   static __device__ __forceinline__ void run(const GemmP& p, int wg) {
     if (threadIdx.x >= 64) return;
+    __builtin_amdgcn_s_setprio(3);
     RunCtx* cx = p.ctx;
     if (step_done(cx, p.step_in_chunk)) return;  // (the producers skip their epilogue under the same test)
     const int lane = threadIdx.x;
