@@ -488,7 +488,11 @@ def main():
         wl.run()
 
     # stage split and decoder-step roofline from HIP events on the launch stream (untimed extra passes)
+    # (each recorded pass is enqueued behind an unrecorded one that is still executing, so that the events bracket
+    # the GPU time of a stage and not the host's launch rate on an empty queue - the timed loop above runs the
+    # same way, the host ahead of the device)
     for _ in range(2):
+        wl.run()
         wl.run(record=True)
     st = wl.stages()
     dec_us = st["decoder"] * 1e3 / S

@@ -290,6 +290,15 @@ int ttsx_encoder_lstm_run(ttsx_encoder_lstm* p, const float* x, const int32_t* l
 int ttsx_encoder_lstm_run_stateful(ttsx_encoder_lstm* p, const float* x, const int32_t* lengths, int B, int T,
                                    float* out, float* h_state, float* c_state, void* stream);
 
+/* How the recurrence of the following runs is executed (no reference counterpart): 1 = as one persistent launch
+ * over all T steps of both directions (a workgroup per row block keeps its slice of W_hh and its cell states in
+ * registers; h(t) travels between them through step counters), wherever all of its workgroups fit the chip at once
+ * (up to 128 padded utterance columns); 0 = as a chain of T step launches; -1 (default) = the persistent launch at
+ * batch 1-2, where it measured faster (3.0 against 4.2 ms for 1000 symbols), and the chain after a launch whose
+ * workgroups were not resident together (bounded waits).  With the persistent launch ttsx_encoder_lstm_run*
+ * synchronise `stream`. */
+int ttsx_encoder_lstm_set_plan(ttsx_encoder_lstm* lstm, int scan);
+
 /* Tacotron2._add_speaker_embedding (models.py:838-849): enc[b][t][:] += table[speaker_ids[b]][:].
  *   enc [B,T,512] in place, table = speaker_embedding.weight [n_speakers,512], speaker_ids [B] int32. */
 int ttsx_add_speaker_embedding(float* enc, const float* table, const int32_t* speaker_ids, int n_speakers, int B,

@@ -71,6 +71,7 @@ def test_entry_points_reject_bad_arguments_before_any_device_call():
         "ttsx_t2_decoder_set_plan": lambda: lib.ttsx_t2_decoder_set_plan(None, -1, -1, -1),
         "ttsx_t2_decoder_set_team": lambda: lib.ttsx_t2_decoder_set_team(None, -1),
         "ttsx_t2_decoder_set_fusion": lambda: lib.ttsx_t2_decoder_set_fusion(None, -1),
+        "ttsx_t2_decoder_set_pieces": lambda: lib.ttsx_t2_decoder_set_pieces(None, -1),
         "ttsx_t2_decoder_set_polling": lambda: lib.ttsx_t2_decoder_set_polling(None, 0, 0),
         "ttsx_t2_decoder_steps_launched": lambda: lib.ttsx_t2_decoder_steps_launched(None),
         "ttsx_t2_decoder_begin": lambda: lib.ttsx_t2_decoder_begin(None, one, None, 1, 8, None),
@@ -85,6 +86,7 @@ def test_entry_points_reject_bad_arguments_before_any_device_call():
         "ttsx_encoder_lstm_run": lambda: lib.ttsx_encoder_lstm_run(None, one, None, 1, 8, one, None),
         "ttsx_encoder_lstm_run_stateful": lambda: lib.ttsx_encoder_lstm_run_stateful(None, one, None, 1, 8, one, None,
                                                                                      None, None),
+        "ttsx_encoder_lstm_set_plan": lambda: lib.ttsx_encoder_lstm_set_plan(None, -1),
         "ttsx_add_speaker_embedding": lambda: lib.ttsx_add_speaker_embedding(one, one, None, 4, 1, 8, None),
         "ttsx_t1_create": lambda: lib.ttsx_t1_create(None, 5, 5, 1025, None, byref(out)),
         "ttsx_t1_encoder_run": lambda: lib.ttsx_t1_encoder_run(None, one, None, 1, 8, one, None),

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Encoder alone (three conv blocks + BiLSTM): enc_only.py B T -> ms per call (HIP events, best of 5)."""
+"""Encoder alone (three conv blocks + BiLSTM): enc_only.py B T [scan] -> ms per call (HIP events, best of 5);
+scan: -1 by shape, 0 chain of step launches, 1 persistent scan."""
 import os
 import sys
 
@@ -11,15 +12,19 @@ from tts_amd import synthetic  # noqa: E402
 
 B, T = int(sys.argv[1]), int(sys.argv[2])
 model, ap, sd = bench.build_model(0, 1)
+if len(sys.argv) > 3:
+    model.set_encoder_plan(int(sys.argv[3]))
 ids = torch.as_tensor(synthetic.t2_text_ids(5, B, T)).cuda()
-model.encode(ids)
+ref = model.encode(ids)
 torch.cuda.synchronize()
 best = 1e9
 for _ in range(5):
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
-    model.encode(ids)
+    out = model.encode(ids)
     b.record()
     torch.cuda.synchronize()
     best = min(best, a.elapsed_time(b))
-print("encoder B=%d T=%d: %.3f ms" % (B, T, best))
+model.set_encoder_plan(0)
+chain = model.encode(ids)
+print("encoder B=%d T=%d: %.3f ms; max |scan - chain| = %.2e" % (B, T, best, float((out - chain).abs().max())))

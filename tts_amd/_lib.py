@@ -117,6 +117,7 @@ PROTOTYPES = {
     "ttsx_encoder_lstm_destroy": (c_int, [c_void_p]),
     "ttsx_encoder_lstm_run": (c_int, [c_void_p, _fp, _fp, c_int, c_int, _fp, c_void_p]),
     "ttsx_encoder_lstm_run_stateful": (c_int, [c_void_p, _fp, _fp, c_int, c_int, _fp, _fp, _fp, c_void_p]),
+    "ttsx_encoder_lstm_set_plan": (c_int, [c_void_p, c_int]),
     "ttsx_add_speaker_embedding": (c_int, [_fp, _fp, _fp, c_int, c_int, c_int, c_void_p]),
     "ttsx_t1_create": (c_int, [POINTER(T1Weights), c_int, c_int, c_int, c_void_p, POINTER(c_void_p)]),
     "ttsx_t1_destroy": (c_int, [c_void_p]),

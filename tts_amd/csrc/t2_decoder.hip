@@ -53,6 +53,7 @@
 #include <vector>
 
 #include "common.h"
+#include "enc_scan.h"
 #include "t2_team.h"
 
 namespace {
@@ -561,7 +562,7 @@ struct GemmOp {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0)
           __hip_atomic_store(p.x1_flags + (b0 / 16 + wave) * (PRENET_DIM / 16) + xb,
-                             (unsigned)(p.ctx->base + p.step_in_chunk + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                             (unsigned)(p.ctx->base + p.step_in_chunk + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
     if (qshare) {
@@ -820,8 +821,10 @@ struct Prenet2AfterProjOp {
       if (lane == 0) cx->sync_failed = 1;
       return;
     }
-    // pairs with the release store of the flags: the x1 reads below are ordered after the flag reads
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    // (No acquire fence here and no release store on the producer's side: at agent scope they invalidate / write
+    // back the L2 - measured +0.7 us on this launch.  x1 and the flags only move through agent-scope accesses that
+    // bypass the caches which such fences would maintain; the producer waits for its x1 stores to be acknowledged
+    // (vmcnt) before it raises the flag, and the x1 loads below are issued after the flag loads have returned.)
     // B fragments: lane l holds x1[16 kg + 4 (l >> 4) + s][b0 + (l & 15)], s = 0..3 (one quad of the quad layout)
     const unsigned long long* X = reinterpret_cast<const unsigned long long*>(p.seg[0].x[0]) +
                                   ((size_t)(lane >> 4) * p.Bpad + b0 + (lane & 15)) * 2;
@@ -3035,16 +3038,26 @@ struct ttsx_encoder_lstm {
   // workspace
   int cap_B, cap_T, Bc, Ct;
   float *xq, *gi[2], *h[2][2], *c[2];
+  // the recurrence as one persistent launch (enc_scan.hip)
+  float* scan_hx;
+  unsigned* scan_steps;
+  int* scan_abort;
+  int plan_scan;            // ttsx_encoder_lstm_set_plan: -1 by shape (default), 0 launch chain, 1 scan wherever possible
+  TeamCoolDown scan_cool;   // a scan whose workgroups were not resident together: launch chain for a while
 };
 
 namespace {
 
 void enc_lstm_free_ws(ttsx_encoder_lstm* e) {
-  float** bufs[] = {&e->xq, &e->gi[0], &e->gi[1], &e->h[0][0], &e->h[0][1], &e->h[1][0], &e->h[1][1], &e->c[0], &e->c[1]};
+  float** bufs[] = {&e->xq, &e->gi[0], &e->gi[1], &e->h[0][0], &e->h[0][1], &e->h[1][0], &e->h[1][1], &e->c[0], &e->c[1],
+                    &e->scan_hx};
   for (float** b : bufs) {
     if (*b) (void)hipFree(*b);
     *b = nullptr;
   }
+  if (e->scan_steps) (void)hipFree(e->scan_steps);
+  if (e->scan_abort) (void)hipFree(e->scan_abort);
+  e->scan_steps = nullptr, e->scan_abort = nullptr;
   e->cap_B = e->cap_T = 0;
 }
 
@@ -3054,7 +3067,18 @@ int enc_launch_one(const GemmP& g, int nrb, int Bc, int cols, hipStream_t st) {
   const int nt_total = cols / 16;
   if (Bc == 1 && MODE == MODE_LSTM) dual_kernel<GemvOp<1, KGW, MODE>, NoOp><<<nrb, GEMM_THREADS, 0, st>>>(g, 0, nrb);
   else if (Bc == 2 && MODE == MODE_LSTM) dual_kernel<GemvOp<2, KGW, MODE>, NoOp><<<nrb, GEMM_THREADS, 0, st>>>(g, 0, nrb);
-  else if (nt_total % 2 == 0 && nrb / 2 * (nt_total / 2) >= 256) {
+  else if (MODE == MODE_PARTIAL && nrb % 4 == 0 && nt_total % 4 == 0 && nrb / 4 * (nt_total / 4) >= 512) {
+    // the input projection of a whole batch (thousands of columns): 64 x 64 tiles, combine buffer in dynamic LDS
+    typedef GemmOp<4, 4, KGW, MODE, true> Op;
+    static bool raised = false;
+    if (!raised) {
+      TTSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dual_kernel<Op, NoOp>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM44_LDS_BYTES));
+      raised = true;
+    }
+    const int n = nrb / 4 * (nt_total / 4);
+    dual_kernel<Op, NoOp><<<n, GEMM_THREADS, GEMM44_LDS_BYTES, st>>>(g, 0, n);
+  } else if (nt_total % 2 == 0 && nrb / 2 * (nt_total / 2) >= 256) {
     const int n = nrb / 2 * (nt_total / 2);
     dual_kernel<GemmOp<2, 2, KGW, MODE>, NoOp><<<n, GEMM_THREADS, 0, st>>>(g, 0, n);
   } else {
@@ -3071,7 +3095,7 @@ extern "C" int ttsx_encoder_lstm_create(const ttsx_encoder_lstm_weights* w, void
   TTSX_ARG(w && out, "ttsx_encoder_lstm_create: null argument");
   hipStream_t st = static_cast<hipStream_t>(stream);
   ttsx_encoder_lstm* e = new ttsx_encoder_lstm();
-  memset(e, 0, sizeof(*e));
+  e->plan_scan = -1;
   ScopeExit on_fail([&] { (void)ttsx_encoder_lstm_destroy(e); });
   int rc = 0;
   for (int d = 0; d < 2; ++d) {
@@ -3102,6 +3126,13 @@ extern "C" int ttsx_encoder_lstm_destroy(ttsx_encoder_lstm* e) {
   return TTSX_OK;
 }
 
+extern "C" int ttsx_encoder_lstm_set_plan(ttsx_encoder_lstm* e, int scan) {
+  TTSX_ARG(e, "ttsx_encoder_lstm_set_plan: null handle");
+  TTSX_ARG(scan >= -1 && scan <= 1, "ttsx_encoder_lstm_set_plan: the argument is -1 (by shape), 0 or 1");
+  e->plan_scan = scan;
+  return TTSX_OK;
+}
+
 extern "C" int ttsx_encoder_lstm_run(ttsx_encoder_lstm* e, const float* x, const int32_t* lengths, int B, int T,
                                      float* out, void* stream) {
   return ttsx_encoder_lstm_run_stateful(e, x, lengths, B, T, out, nullptr, nullptr, stream);
@@ -3125,6 +3156,11 @@ extern "C" int ttsx_encoder_lstm_run_stateful(ttsx_encoder_lstm* e, const float*
       rc |= dev_alloc(&e->c[d], (size_t)ENC_H * Bc);
       for (int i = 0; i < 2; ++i) rc |= dev_alloc(&e->h[d][i], (size_t)ENC_H * Bc);
     }
+    if (enc_scan_supports(Bc)) {
+      rc |= dev_alloc(&e->scan_hx, enc_scan_hx_floats(Bc));
+      rc |= dev_alloc(&e->scan_steps, enc_scan_step_words(Bc));
+      rc |= dev_alloc(&e->scan_abort, 1);
+    }
     if (rc) return TTSX_ERR_HIP;
     e->cap_B = Bc, e->cap_T = T;
   }
@@ -3136,6 +3172,30 @@ extern "C" int ttsx_encoder_lstm_run_stateful(ttsx_encoder_lstm* e, const float*
     TTSX_LAUNCH_CHECK();
   }
   int rc;
+  // The recurrence as one persistent launch (enc_scan.hip) or as a chain of T step launches.  Measured, encoder
+  // in all (scan / chain, the chain's launches queued ahead of the GPU): B=1 T=100 0.46 / 0.50 ms, T=300 1.03 / 1.25,
+  // T=1000 3.05 / 4.16; B=2 T=60 0.35 / 0.36; B=16 T=77 0.55 / 0.55; B=32 T=50 0.56 / 0.53; B=64 T=128 1.73 / 1.63:
+  // a step of the scan is two memory-side round trips (counters, then h) plus the store acknowledgement, 2.7 us at
+  // one utterance and 4.7 us at 64 (every workgroup reads all of h past the L2), a queued step launch 3.9 / 3.8 us.
+  // By shape: the scan at batch 1-2.
+  const bool by_shape = B <= GEMV_MAX_B && !e->scan_cool.cooling();
+  const bool scan = e->scan_hx && enc_scan_supports(Bc) && (e->plan_scan == 1 || (e->plan_scan == -1 && by_shape));
+  if (scan) {
+    EncScanArgs a{};
+    for (int d = 0; d < 2; ++d) {
+      GemmP g{};
+      g.Wp = e->w_ih[d], g.nseg = 1, g.KG = ENC_IN / 16, g.Bpad = Ct, g.kg0 = 0, g.kg_stride = ENC_IN / 16;
+      g.rb0 = 0, g.nrb = ENC_H / 4, g.seg[0] = Seg{{e->xq, nullptr}, 0, ENC_IN / 16};
+      g.gates = e->gi[d], g.ctx = e->rc;
+      if ((rc = enc_launch_one<MODE_PARTIAL, ENC_IN / 16 / GEMM_WAVES>(g, ENC_H / 4, Bc, Ct, st))) return rc;
+      a.w_hh[d] = e->w_hh[d], a.bias[d] = e->bias[d], a.gi[d] = e->gi[d];
+    }
+    a.hx = e->scan_hx, a.steps = e->scan_steps, a.abort_word = e->scan_abort;
+    a.out = out, a.len = lengths, a.h_state = h_state, a.c_state = c_state, a.T = T, a.B = B, a.Bc = Bc, a.Ct = Ct;
+    rc = enc_scan_run(a, st);
+    if (rc != TTSX_ERR_STATE || e->plan_scan == 1) return rc;
+    e->scan_cool.start();   // (h_state / c_state are only written by the last step of a scan that ran through)
+  }
   for (int d = 0; d < 2; ++d) {
     TTSX_HIP(hipMemsetAsync(e->h[d][0], 0, sizeof(float) * ENC_H * Bc, st));
     TTSX_HIP(hipMemsetAsync(e->c[d], 0, sizeof(float) * ENC_H * Bc, st));

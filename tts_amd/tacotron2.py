@@ -333,6 +333,11 @@ class Tacotron2:
         _lib.check(_lib.load().ttsx_t2_decoder_set_fusion(self._dec_handle, int(prenet_in_projection)),
                    "ttsx_t2_decoder_set_fusion")
 
+    def set_encoder_plan(self, scan=-1):
+        """Encoder BiLSTM recurrence as one persistent launch (1), as a chain of step launches (0), or by shape (-1)
+        (ttsx_encoder_lstm_set_plan)."""
+        _lib.check(_lib.load().ttsx_encoder_lstm_set_plan(self._lstm_handle, int(scan)), "ttsx_encoder_lstm_set_plan")
+
     def set_pieces(self, staged=-1):
         """Padded batch 64: early-column pieces as 32 x 32 register tiles (0) or staged through LDS (1)
         (ttsx_t2_decoder_set_pieces); -1 by shape."""
