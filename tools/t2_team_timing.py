@@ -26,7 +26,7 @@ t = list(out)
 names = {0: "proj: h_d + ctx of step 49 arrived", 1: "proj: x1 published", 2: "proj: x1 arrived", 3: "proj: x2 published",
          8: "att: x2 arrived", 9: "att: h_a published", 16: "energy: h_a arrived", 17: "energy: partial energies published",
          18: "energy: all partial energies arrived", 19: "energy: alignment state updated", 24: "ctx: partial energies arrived",
-         25: "ctx: context published", 32: "dec: h_a arrived", 33: "dec: context arrived", 34: "dec: h_d published"}
+         25: "ctx: context published", 32: "dec: h_a arrived", 33: "dec: partial energies arrived", 34: "dec: h_d published"}
 t0 = t[0]
 for i in sorted(names, key=lambda i: t[i]):
     print("%8.2f us  %s" % ((t[i] - t0) / 100.0, names[i]))

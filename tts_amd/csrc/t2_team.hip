@@ -8,8 +8,9 @@
 // 216 workgroups (one per CU, 512 threads each) keeps all of it on chip for the whole utterance:
 //   *  64 attention-LSTM workgroups, 16 hidden units each (a wave owns 2 units = 8 gate rows): the columns over
 //      the prenet output and over h_a(t-1) in registers (160 per thread), the columns over the context in LDS;
-//   * 128 decoder-LSTM workgroups, 8 hidden units each (a wave owns one unit): the columns over h_a and the
-//      context in registers (96 per thread), the columns over h_d(t-1) in LDS;
+//   * 128 decoder-LSTM workgroups, 8 hidden units each (a wave owns one unit): the columns over h_a in registers
+//      (64 per thread), the columns over h_d(t-1) in LDS, and - instead of the columns over the context - their
+//      products with the utterance's encoder outputs, one per position (see below);
 //   *  16 projection workgroups: the mel rows, the composed stop-logit row, the composed prenet-layer-1 rows and
 //      prenet layer 2, all in registers;
 //   *   4 energy workgroups, one per 32 attention dimensions: their rows of the query layer in registers, the
@@ -22,9 +23,15 @@
 // that its consumers add in a fixed order.
 // Only activations cross the chip, as in the Tacotron (v1) team kernel (t1_team.hip): 64-bit words (step tag,
 // fp32 value) in small exchange buffers, written with one contiguous store per workgroup and vector, polled once
-// per workgroup (thread i polls word i) and handed on through LDS.  Six exchanges lie on a step's serial chain:
-// x1 | x2 | h_a | partial energies | context | h_d.  Everything that depends on the previous step only (the
+// per workgroup (thread i polls word i) and handed on through LDS.  Five exchanges lie on a step's serial chain:
+// x1 | x2 | h_a | partial energies | h_d.  Everything that depends on the previous step only (the
 // recurrent columns of both LSTMs, the location features) is evaluated while the chain is elsewhere.
+// The context is off that chain: it is a weighted sum of encoder outputs, ctx = sum_p a[p] enc[p], so what the
+// decoder LSTM needs of it is W_c ctx = sum_p a[p] (W_c enc[p]).  The products G[row][p] = W_c[row] . enc[p] are
+// formed once per utterance (ctx_gates_kernel) and held in registers; a decoder-LSTM workgroup takes the partial
+// energies themselves, normalises them like every attention workgroup does (same operations, same order) and
+// adds sum_p a[p] G[row][p] - it never waits for the context workgroups, whose output goes to the projection and
+// to the next step's attention LSTM, both of which need it later than the decoder LSTM did.
 // A free run ends through the data: the workgroup that owns the stop row marks the words it publishes, and every
 // workgroup that sees a marked word marks what it publishes and leaves.  Every wait is bounded: a team that is not
 // resident together (other kernels hold CUs) raises an abort word after ~2 s and the host reports it.
@@ -49,7 +56,7 @@ constexpr int PROJ_K = DD + ED;
 
 // register images: slot s of thread tid of workgroup g of a role at img[(g * NS + s) * NT + tid]
 constexpr int A_X2 = 0, A_HA = 32, A_B = 160, NS_ATT = 168;   // row ri = 4 * unit_in_wave + gate
-constexpr int D_HA = 0, D_CTX = 64, D_B = 96, NS_DEC = 100;   // row = gate
+constexpr int D_HA = 0, D_B = 64, NS_DEC = 68;   // row = gate
 constexpr int P_ROW = 0, P_B = 120, P_W2 = 125, P_B2 = 133, NS_PROJ = 135;
 constexpr int NS_EN = 64;
 constexpr int LDS_W = 32768;  // floats of weights in the LDS of an LSTM workgroup
@@ -62,6 +69,7 @@ constexpr int X_HA = 0, X_CTX = X_HA + QD, X_HD = X_CTX + NC_MAX * ED, X_X1 = X_
 
 struct T2P {
   const float *img_att, *lds_att, *img_dec, *lds_dec, *img_proj, *img_en;
+  const float* ctx_gates;  // [1024 units][4 gates][TS positions]: decoder-LSTM context columns x encoder outputs
   const float *conv_t /* [62][32] */, *loc_dense /* [128][32] */, *v_w, *v_b, *b1f;
   const float *enc, *P;
   const int32_t* len;
@@ -327,24 +335,34 @@ __device__ void att_role(const T2P& p, int a, float* sm) {
 }
 
 // ------------------------------------------------------------------ decoder LSTM: 8 hidden units
-template <int NC>
+// TS = positions the team's attention roles are built for (128, 256 or NC * 256).  Lane l of every wave holds
+// positions l + 64 j: the alignment weights are formed per wave, with the operations and the order of summation
+// of normalise<TM> (NC == 1) / normalise_all<NC>, so they are the numbers the attention workgroups get.
+template <int TM, int NC>
 __device__ void dec_role(const T2P& p, int d, float* sm) {
+  constexpr int TS = NC == 1 ? TM : NC * 256, NJ = TS / 64;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   float* s_wh = sm;                 // [wave][4 rows][16][64] columns over h_d(t-1)
   float* s_hd = s_wh + LDS_W;       // [1024]
   float* s_ha = s_hd + DD;          // [1024]
-  float* s_ctx = s_ha + QD;         // [NC][512]
-  float* s_pub = s_ctx + NC * ED;   // [8]
+  float* s_e4 = s_ha + QD;          // [4][TS] partial energies
+  float* s_pub = s_e4 + N_EN * TS;  // [8]
   int* s_flag = reinterpret_cast<int*>(s_pub + 8);
-  float w[NS_DEC];
+  const int len = min(max(p.len[0], 0), p.T);
+  float w[NS_DEC], wm[4 * NJ];
   {
     const float* img = p.img_dec + ((size_t)d * NS_DEC) * NT + tid;
 #pragma unroll
     for (int s = 0; s < NS_DEC; ++s) w[s] = img[(size_t)s * NT];
+    const float* G = p.ctx_gates + (size_t)(8 * d + wave) * 4 * TS + lane;
+#pragma unroll
+    for (int s = 0; s < 4 * NJ; ++s) wm[s] = G[(size_t)(s / NJ) * TS + 64 * (s % NJ)];
   }
   for (int i = tid; i < LDS_W; i += NT) s_wh[i] = p.lds_dec[(size_t)d * LDS_W + i];
   if (tid == 0) *s_flag = 0;
+  const float vb = p.v_b[0];
+  const bool softmax = p.norm == TTSX_NORM_SOFTMAX;
   __syncthreads();
   const float* wh = s_wh + (size_t)wave * 4 * 16 * 64 + lane;
   float cc[1] = {0.f}, hh[1] = {0.f};
@@ -384,22 +402,54 @@ __device__ void dec_role(const T2P& p, int d, float* sm) {
         acc[g] = s;
       }
     }
-    // ---- the columns over the context, the cell update
-    if (fetch_span<NC>(Xc + X_CTX, NC * ED, tag, s_ctx, p.abort_word, s_flag) & 1) return;
-    T2_MARK(d == 0, 33);
+    // ---- the context's share from the partial energies, the cell update
     {
-      float cv[8], g4[4];
+      const int st = fetch_span<N_EN * TS / NT>(Xc + X_EP, N_EN * TS, tag, s_e4, p.abort_word, s_flag);
+    T2_MARK(d == 0, 33);
+      if (st & 1) return;
+      if (st & 2) break;
+    }
+    {
+      float v[NJ];
+      float m = 0.f;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        cv[j] = s_ctx[lane + 64 * j];
-#pragma unroll
-        for (int c = 1; c < NC; ++c) cv[j] += s_ctx[c * ED + lane + 64 * j];
+      for (int j = 0; j < NJ; ++j) {
+        const int i = lane + 64 * j;
+        v[j] = ((s_e4[i] + s_e4[TS + i]) + (s_e4[2 * TS + i] + s_e4[3 * TS + i])) + vb;
       }
+      if (softmax) {
+        float x = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) x = fmaxf(x, lane + 64 * j < len ? v[j] : -INFINITY);
+        m = wmax(x);
+      }
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) v[j] = lane + 64 * j < len ? (softmax ? expf(v[j] - m) : sigmoidf_(v[j])) : 0.f;
+      float sum;
+      if constexpr (NC == 1) {
+        // normalise<TM>: wave j of the attention workgroup adds positions 64 j ... 64 j + 63; the wave sums in order
+        sum = wsum(v[0]);
+#pragma unroll
+        for (int j = 1; j < NJ; ++j) sum += wsum(v[j]);
+      } else {
+        // normalise_all<NC>: thread tid adds its positions tid + 512 j, wave w = tid / 64 sums them; in wave order
+        static_assert(NJ % 8 == 0, "whole rounds of 512 positions");
+        sum = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < 8; ++wv) {
+          float part = 0.f;
+#pragma unroll
+          for (int j = 0; j < NJ / 8; ++j) part += v[wv + 8 * j];
+          const float ws = wsum(part);
+          sum = wv == 0 ? ws : sum + ws;
+        }
+      }
+      float g4[4];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         float s = acc[g];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) s += w[D_CTX + g * 8 + j] * cv[j];
+        for (int j = 0; j < NJ; ++j) s += wm[g * NJ + j] * (v[j] / sum);
         g4[g] = wsum(s) + w[D_B + g];
       }
       hh[0] = lstm_cell(g4[0], g4[1], g4[2], g4[3], &cc[0]);
@@ -846,6 +896,7 @@ __device__ void energy_long_role(const T2P& p, int ge, float* sm) {
     const unsigned tag = (unsigned)t + 1u;
     u64* Xc = p.xch + (size_t)(t & 1) * X_PAR;
     const int st = fetch_span<2>(Xc + X_HA, QD, tag, s_ha, p.abort_word, s_flag);
+    T2_MARK(ge == 0, 16);
     if (st & 1) return;
     if (st & 2) {
       if (tid < 256) publish(Xc + X_EP, e * TS + base + tid, 0.f, tag | DONE_BIT);
@@ -879,8 +930,10 @@ __device__ void energy_long_role(const T2P& p, int ge, float* sm) {
     }
     __syncthreads();
     if (tid < 256) publish(Xc + X_EP, e * TS + base + tid, s_ep[tid] + s_ep[256 + tid], tag);
+    T2_MARK(ge == 0, 17);
     // ---- off the serial chain: this step's alignment over all positions
     if (fetch_span<4 * TS / NT>(Xc + X_EP, 4 * TS, tag, s_e4, p.abort_word, s_flag) & 1) return;
+    T2_MARK(ge == 0, 18);
     normalise_all<NC>(s_e4, vb, len, p.norm, s_al, s_red);
     __syncthreads();
 #pragma unroll
@@ -893,6 +946,7 @@ __device__ void energy_long_role(const T2P& p, int ge, float* sm) {
     }
     __syncthreads();
     location_terms();
+    T2_MARK(ge == 0, 19);
   }
 }
 
@@ -922,6 +976,7 @@ __device__ void ctx_long_role(const T2P& p, int gc, float* sm) {
     const unsigned tag = (unsigned)t + 1u;
     u64* Xc = p.xch + (size_t)(t & 1) * X_PAR;
     const int st = fetch_span<4 * TS / NT>(Xc + X_EP, 4 * TS, tag, s_e4, p.abort_word, s_flag);
+    T2_MARK(gc == 0, 24);
     if (st & 1) return;
     if (st & 2) break;
     normalise_all<NC>(s_e4, vb, len, p.norm, s_al, s_red);
@@ -940,6 +995,7 @@ __device__ void ctx_long_role(const T2P& p, int gc, float* sm) {
     __syncthreads();
     if (tid < 128)
       publish(Xc + X_CTX, chunk * ED + 128 * cs + tid, (s_cp[tid] + s_cp[128 + tid]) + (s_cp[256 + tid] + s_cp[384 + tid]), tag);
+    T2_MARK(gc == 0, 25);
   }
 }
 
@@ -949,7 +1005,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   const int g = blockIdx.x;
   constexpr int g_ctx0 = G_EN0 + N_EN * NC;
   if (g < G_DEC0) att_role<NC>(p, g, sm);
-  else if (g < G_PROJ0) dec_role<NC>(p, g - G_DEC0, sm);
+  else if (g < G_PROJ0) dec_role<TM, NC>(p, g - G_DEC0, sm);
   else if (g < G_EN0) proj_role<NC>(p, g - G_PROJ0, sm);
   else if constexpr (NC == 1) {
     if (g < g_ctx0) energy_role<TM>(p, g - G_EN0, sm);
@@ -961,7 +1017,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 }
 
 constexpr size_t LDS_ATT = (size_t)(LDS_W + PD + QD + NC_MAX * ED + 16 + 8) * sizeof(float);
-constexpr size_t LDS_DEC = (size_t)(LDS_W + DD + QD + NC_MAX * ED + 8 + 8) * sizeof(float);
+constexpr size_t LDS_DEC = (size_t)(LDS_W + DD + QD + N_EN * NC_MAX * 256 + 8 + 8) * sizeof(float);
+static_assert(LDS_DEC <= 160 * 1024, "a decoder-LSTM workgroup's LDS");
 constexpr size_t LDS_EN = (size_t)(2 * LOCK * LOCF + 32 * LOCF + 32 + 2 * (TMAX + 32) + TMAX * (LOCF + 1) + QD + 32 +
                                    4 * TMAX + N_EN * TMAX + 8 + 8) * sizeof(float);
 constexpr size_t TEAM_LDS = LDS_ATT > LDS_DEC ? (LDS_ATT > LDS_EN ? LDS_ATT : LDS_EN) : (LDS_DEC > LDS_EN ? LDS_DEC : LDS_EN);
@@ -969,7 +1026,7 @@ constexpr size_t TEAM_LDS = LDS_ATT > LDS_DEC ? (LDS_ATT > LDS_EN ? LDS_ATT : LD
 // ---- packing
 struct PackP {
   T2TeamWeights w;
-  float *img_att, *lds_att, *img_dec, *lds_dec, *img_en, *conv_t, *loc_dense;
+  float *img_att, *lds_att, *img_dec, *lds_dec, *img_en, *conv_t, *loc_dense, *ctx_cols;
 };
 
 __global__ void pack_lstm_kernel(PackP p) {
@@ -1002,12 +1059,9 @@ __global__ void pack_lstm_kernel(PackP p) {
     const int tid = (int)(i % NT), s = (int)((i / NT) % NS_DEC), d = (int)(i / ((size_t)NT * NS_DEC));
     const int lane = tid & 63, wave = tid >> 6, u = 8 * d + wave;
     float v;
-    if (s < D_CTX) {
+    if (s < D_B) {
       const int g = s / 16, j = s % 16;
       v = p.w.dec_w_ih[(size_t)(g * DD + u) * KD + lane + 64 * j];
-    } else if (s < D_B) {
-      const int g = (s - D_CTX) / 8, j = (s - D_CTX) % 8;
-      v = p.w.dec_w_ih[(size_t)(g * DD + u) * KD + QD + lane + 64 * j];
     } else {
       const int g = s - D_B;
       v = p.w.dec_b_ih[g * DD + u] + p.w.dec_b_hh[g * DD + u];
@@ -1019,6 +1073,11 @@ __global__ void pack_lstm_kernel(PackP p) {
     const int lane = (int)(i & 63), j = (int)((i >> 6) & 15), g = (int)((i >> 10) & 3), wave = (int)((i >> 12) & 7);
     const int d = (int)(i / LDS_W), u = 8 * d + wave;
     p.lds_dec[i] = p.w.dec_w_hh[(size_t)(g * DD + u) * DD + lane + 64 * j];
+  }
+  if (i < (size_t)4 * DD * ED) {
+    // [unit][gate][k]: decoder_rnn.weight_ih's columns over the context
+    const int k = (int)(i % ED), g = (int)((i / ED) & 3), u = (int)(i / (4 * ED));
+    p.ctx_cols[i] = p.w.dec_w_ih[(size_t)(g * DD + u) * KD + QD + k];
   }
   if (i < (size_t)N_EN * NS_EN * NT) {
     const int tid = (int)(i % NT), s = (int)((i / NT) % NS_EN), e = (int)(i / ((size_t)NT * NS_EN));
@@ -1061,10 +1120,51 @@ __global__ void pack_proj_kernel(float* __restrict__ img, const float* __restric
   img[i] = v;
 }
 
+// G[row][p] = W_c[row] . enc[p] for the 4096 rows (unit, gate) of the decoder LSTM's context columns and the TS
+// positions the team is built for (zero beyond the utterance's own length): once per run, before the team starts.
+// A wave forms 16 rows x 64 positions on v_mfma_f32_16x16x4_f32; lane l supplies row / position l & 15 and, for
+// the four instructions of a 16-byte load, K index 16 i + 4 (l >> 4) + s on both sides.
+__global__ __launch_bounds__(256) void ctx_gates_kernel(const float* __restrict__ Wc, const float* __restrict__ enc,
+                                                         const int32_t* __restrict__ len_p, int T, int TS, float* __restrict__ G) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int rb = blockIdx.x * 4 + wave, pb = blockIdx.y;
+  const int r = lane & 15, kq = lane >> 4;
+  const int len = min(max(len_p[0], 0), T);
+  const f32x4* A = reinterpret_cast<const f32x4*>(Wc + (size_t)(16 * rb + r) * ED) + kq;
+  const f32x4* Bp[4];
+  bool in[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int pos = 64 * pb + 16 * c + r;
+    in[c] = pos < len;
+    Bp[c] = reinterpret_cast<const f32x4*>(enc + (size_t)(in[c] ? pos : 0) * ED) + kq;
+  }
+  f32x4 acc[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+  for (int i = 0; i < ED / 16; ++i) {
+    const f32x4 a = A[4 * i];
+    f32x4 b[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) b[c] = Bp[c][4 * i];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[c][s], acc[c], 0, 0, 0);
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      G[(size_t)(16 * rb + 4 * kq + i) * TS + 64 * pb + 16 * c + r] = in[c] ? acc[c][i] : 0.f;
+}
+
 }  // namespace
 
 struct t2_team {
   float *img_att, *lds_att, *img_dec, *lds_dec, *img_proj, *img_en, *conv_t, *loc_dense;
+  float *ctx_cols, *ctx_gates;  // [4096][512] context columns of the decoder LSTM; their products with one utterance
   float *v_w, *v_b, *b1f, *a2f, *b2f;  // own copies
   int proj_r;
   u64* xch;
@@ -1103,16 +1203,17 @@ int t2_team_create(const T2TeamWeights* w, hipStream_t st, t2_team** out) {
   TTSX_HIP(alloc(&t->img_en, (size_t)N_EN * NS_EN * NT));
   TTSX_HIP(alloc(&t->conv_t, (size_t)LOCF * 2 * LOCK));
   TTSX_HIP(alloc(&t->loc_dense, (size_t)AD * LOCF));
+  TTSX_HIP(alloc(&t->ctx_cols, (size_t)4 * DD * ED));
+  TTSX_HIP(alloc(&t->ctx_gates, (size_t)4 * DD * NC_MAX * 256));
   TTSX_HIP(hipMalloc(reinterpret_cast<void**>(&t->xch), sizeof(u64) * 2 * X_PAR));
   TTSX_HIP(hipMalloc(reinterpret_cast<void**>(&t->abort_word), sizeof(int)));
   int rc;
   if ((rc = dup(&t->v_w, w->v_w, AD, st)) || (rc = dup(&t->v_b, w->v_b, 1, st)) || (rc = dup(&t->b1f, w->b1f, PD, st)) ||
       (rc = dup(&t->a2f, w->a2f, (size_t)PD * PD, st)) || (rc = dup(&t->b2f, w->b2f, PD, st)))
     return rc;
-  PackP pp{*w, t->img_att, t->lds_att, t->img_dec, t->lds_dec, t->img_en, t->conv_t, t->loc_dense};
-  const size_t n = (size_t)N_DEC * NS_DEC * NT;  // the largest of the index ranges
-  static_assert((size_t)N_DEC * NS_DEC * NT >= (size_t)N_ATT * NS_ATT * NT && (size_t)N_DEC * NS_DEC * NT >= (size_t)N_DEC * LDS_W,
-                "pack_lstm_kernel's grid covers every image");
+  PackP pp{*w, t->img_att, t->lds_att, t->img_dec, t->lds_dec, t->img_en, t->conv_t, t->loc_dense, t->ctx_cols};
+  const size_t n = std::max({(size_t)N_ATT * NS_ATT * NT, (size_t)N_DEC * NS_DEC * NT, (size_t)N_DEC * LDS_W,
+                             (size_t)N_ATT * LDS_W, (size_t)4 * DD * ED, (size_t)N_EN * NS_EN * NT});  // every index range
   pack_lstm_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(pp);
   TTSX_LAUNCH_CHECK();
   for (const void* k : {reinterpret_cast<const void*>(t2_team_kernel<128, 1>), reinterpret_cast<const void*>(t2_team_kernel<256, 1>),
@@ -1127,7 +1228,7 @@ int t2_team_create(const T2TeamWeights* w, hipStream_t st, t2_team** out) {
 void t2_team_destroy(t2_team* t) {
   if (!t) return;
   float* bufs[] = {t->img_att, t->lds_att, t->img_dec, t->lds_dec, t->img_proj, t->img_en, t->conv_t,
-                   t->loc_dense, t->v_w, t->v_b, t->b1f, t->a2f, t->b2f};
+                   t->loc_dense, t->ctx_cols, t->ctx_gates, t->v_w, t->v_b, t->b1f, t->a2f, t->b2f};
   for (float* b : bufs)
     if (b) (void)hipFree(b);
   if (t->xch) (void)hipFree(t->xch);
@@ -1170,6 +1271,7 @@ int t2_team_run(t2_team* t, const float* enc, const float* P, const int32_t* len
   p.img_att = t->img_att, p.lds_att = t->lds_att, p.img_dec = t->img_dec, p.lds_dec = t->lds_dec;
   p.img_proj = t->img_proj, p.img_en = t->img_en, p.conv_t = t->conv_t, p.loc_dense = t->loc_dense;
   p.v_w = t->v_w, p.v_b = t->v_b, p.b1f = t->b1f, p.enc = enc, p.P = P, p.len = len, p.xch = t->xch;
+  p.ctx_gates = t->ctx_gates;
   p.abort_word = t->abort_word, p.mel = mel, p.align = align, p.stop = stop, p.n_steps = n_steps;
   if (state_out) p.st = *state_out;
   p.T = T, p.r = r, p.S = max_steps, p.free_run = fixed_steps ? 0 : 1, p.norm = norm, p.thr = stop_threshold;
@@ -1179,6 +1281,9 @@ int t2_team_run(t2_team* t, const float* enc, const float* P, const int32_t* len
   // chip, and every wait is bounded.  (A cooperative launch would refuse a team that cannot be resident, but
   // rocprofv3's kernel trace crashes at exit in a process that has made one.)
   const int grid = G_EN0 + 2 * N_EN * (T <= 256 ? 1 : NC_MAX);
+  const int TS = T <= 128 ? 128 : T <= 256 ? 256 : NC_MAX * 256;
+  ctx_gates_kernel<<<dim3(4 * DD / 64, TS / 64), 256, 0, st>>>(t->ctx_cols, enc, len, T, TS, t->ctx_gates);
+  TTSX_LAUNCH_CHECK();
   if (T <= 128) t2_team_kernel<128, 1><<<grid, NT, TEAM_LDS, st>>>(p);
   else if (T <= 256) t2_team_kernel<256, 1><<<grid, NT, TEAM_LDS, st>>>(p);
   else t2_team_kernel<256, NC_MAX><<<grid, NT, TEAM_LDS, st>>>(p);
