@@ -24,7 +24,7 @@ lib.ttsx_debug_t2_team_timing.restype = ctypes.c_int
 assert lib.ttsx_debug_t2_team_timing(out) == 0
 t = list(out)
 names = {0: "proj: h_d + ctx of step 49 arrived", 1: "proj: x1 published", 2: "proj: x1 arrived", 3: "proj: x2 published",
-         8: "att: x2 arrived", 9: "att: h_a published", 16: "energy: h_a arrived", 17: "energy: partial energies published",
+         8: "att: x2 arrived", 9: "att: h_a published", 10: "att: gate sums ready", 12: "att: after the barrier", 16: "energy: h_a arrived", 17: "energy: partial energies published",
          18: "energy: all partial energies arrived", 19: "energy: alignment state updated", 24: "ctx: partial energies arrived",
          25: "ctx: context published", 32: "dec: h_a arrived", 33: "dec: partial energies arrived", 34: "dec: h_d published"}
 t0 = t[0]

@@ -214,11 +214,17 @@ __device__ __forceinline__ float fast_tanhf(float x) {
   return 1.f - 2.f * __builtin_amdgcn_rcpf(t + 1.f);
 }
 
+// The logistic function through the hardware exponential and reciprocal (1 ulp each; the product x log2(e) inside
+// __expf adds |x| 6e-8 relative to exp(-x), which the factor s (1 - s) of the derivative scales down again:
+// absolute error below 2e-7 everywhere, against 6e-8 for the library's expf and an IEEE division - and four
+// instructions on the step's serial chain instead of some twenty-five).
+__device__ __forceinline__ float fast_sigmoidf(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+
 // torch.nn.LSTMCell from the four gate pre-activations (i, f, g, o) of one hidden unit
 __device__ __forceinline__ float lstm_cell(float gi, float gf, float gg, float go, float* c) {
-  const float c_new = sigmoidf_(gf) * *c + sigmoidf_(gi) * tanhf(gg);
+  const float c_new = fast_sigmoidf(gf) * *c + fast_sigmoidf(gi) * fast_tanhf(gg);
   *c = c_new;
-  return sigmoidf_(go) * tanhf(c_new);
+  return fast_sigmoidf(go) * fast_tanhf(c_new);
 }
 
 // Alignment weights of the utterance's own positions from the summed energies (threads < TM hold one position
@@ -248,6 +254,49 @@ __device__ __forceinline__ float normalise(float e, bool valid, int norm, float*
   return v / sum;
 }
 
+// Alignment weights of ALL NC * 256 positions from the partial energies in LDS ([4][NC * 256]): every energy and
+// context workgroup of a long-text team runs exactly this, then uses its own chunk.  A thread holds positions
+// tid + 512 j.  Called by all threads; the caller synchronises before s_al is read.
+template <int NC>
+__device__ __forceinline__ void normalise_all(const float* s_e4, float vb, int len, int norm, float* s_al, float* s_red) {
+  constexpr int TS = NC * 256, NPT = TS / NT;
+  static_assert(TS % NT == 0, "two chunks per 512 threads");
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const bool softmax = norm == TTSX_NORM_SOFTMAX;
+  float en[NPT];
+#pragma unroll
+  for (int j = 0; j < NPT; ++j) {
+    const int i = tid + NT * j;
+    en[j] = ((s_e4[i] + s_e4[TS + i]) + (s_e4[2 * TS + i] + s_e4[3 * TS + i])) + vb;
+  }
+  float m = 0.f;
+  if (softmax) {
+    float x = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) x = fmaxf(x, tid + NT * j < len ? en[j] : -INFINITY);
+    x = wmax(x);
+    if (lane == 0) s_red[wave] = x;
+    __syncthreads();
+    m = s_red[0];
+#pragma unroll
+    for (int i = 1; i < NT / 64; ++i) m = fmaxf(m, s_red[i]);
+  }
+  float v[NPT], part = 0.f;
+#pragma unroll
+  for (int j = 0; j < NPT; ++j) {
+    v[j] = tid + NT * j < len ? (softmax ? expf(en[j] - m) : sigmoidf_(en[j])) : 0.f;
+    part += v[j];
+  }
+  part = wsum(part);
+  if (lane == 0) s_red[8 + wave] = part;
+  __syncthreads();
+  float sum = s_red[8];
+#pragma unroll
+  for (int i = 1; i < NT / 64; ++i) sum += s_red[8 + i];
+#pragma unroll
+  for (int j = 0; j < NPT; ++j) s_al[tid + NT * j] = v[j] / sum;
+}
+
 // ------------------------------------------------------------------ attention LSTM: 16 hidden units
 template <int NC>
 __device__ void att_role(const T2P& p, int a, float* sm) {
@@ -256,19 +305,27 @@ __device__ void att_role(const T2P& p, int a, float* sm) {
   float* s_wc = sm;                 // [wave][8 rows][8][64] columns over the context
   float* s_x2 = s_wc + LDS_W;       // [256]
   float* s_hc = s_x2 + PD;          // [1024] h_a(t-1), [NC][512] partial contexts of step t-1
-  float* s_pub = s_hc + QD + NC * ED;  // [16]
-  int* s_flag = reinterpret_cast<int*>(s_pub + 16);
+  float* s_g = s_hc + QD + NC * ED;  // [16 units][4] gate pre-activations
+  int* s_flag = reinterpret_cast<int*>(s_g + 64);
+  float* s_w15 = s_g + 64 + 8;        // [8 rows][512]: the last of a row's sixteen slots over h_a(t-1) (off the serial
+                                    // chain; eight registers the allocator would otherwise keep in scratch)
   float w[NS_ATT];
   {
     const float* img = p.img_att + ((size_t)a * NS_ATT) * NT + tid;
 #pragma unroll
-    for (int s = 0; s < NS_ATT; ++s) w[s] = img[(size_t)s * NT];
+    for (int s = 0; s < NS_ATT; ++s) {
+      if (s >= A_HA && s < A_B && (s - A_HA) % 16 == 15) s_w15[(s - A_HA) / 16 * NT + tid] = img[(size_t)s * NT], w[s] = 0.f;
+      else w[s] = img[(size_t)s * NT];
+    }
+    // (the biases are the same on every lane: scalar registers)
+#pragma unroll
+    for (int s = A_B; s < NS_ATT; ++s) w[s] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(w[s])));
   }
   for (int i = tid; i < LDS_W; i += NT) s_wc[i] = p.lds_att[(size_t)a * LDS_W + i];
   if (tid == 0) *s_flag = 0;
   __syncthreads();
   const float* wc = s_wc + (size_t)wave * 8 * 8 * 64 + lane;
-  float cc[2] = {0.f, 0.f}, hh[2] = {0.f, 0.f};
+  float cc = 0.f, hh = 0.f;  // lanes 0-15 of the first wave: the workgroup's sixteen units
   for (int t = 0; t < p.S; ++t) {
     const unsigned tag = (unsigned)t + 1u;
     u64* Xc = p.xch + (size_t)(t & 1) * X_PAR;
@@ -278,21 +335,35 @@ __device__ void att_role(const T2P& p, int a, float* sm) {
 #pragma unroll
     for (int ri = 0; ri < 8; ++ri) acc[ri] = 0.f;
     if (t > 0) {
-      if (fetch_span<(QD + NC * ED) / NT>(Xp + X_HA, QD + NC * ED, tag - 1, s_hc, p.abort_word, s_flag) & 1) return;
+      if constexpr (NC == 1) {
+        if (fetch_span<(QD + ED) / NT>(Xp + X_HA, QD + ED, tag - 1, s_hc, p.abort_word, s_flag) & 1) return;
+      } else {
+        // (two polls: six words per thread in flight next to the weight registers is what the allocator spills)
+        static_assert(X_CTX == X_HA + QD, "h_a and the partial contexts are neighbours");
+        if (fetch_span<QD / NT>(Xp + X_HA, QD, tag - 1, s_hc, p.abort_word, s_flag) & 1) return;
+        if (fetch_span<NC * ED / NT>(Xp + X_CTX, NC * ED, tag - 1, s_hc + QD, p.abort_word, s_flag) & 1) return;
+      }
+      if constexpr (NC > 1) {
+        // the partial contexts added up front, one column per thread (left to the loop below, the 32 operands in
+        // flight pushed weight registers into scratch, and their reloads sat on the serial chain: 0.8 us)
+        static_assert(NT == ED, "one context column per thread");
+        float cs = s_hc[QD + tid];
+#pragma unroll
+        for (int c = 1; c < NC; ++c) cs += s_hc[QD + c * ED + tid];
+        s_hc[QD + tid] = cs;
+        __syncthreads();
+      }
       float hv[16], cv[8];
 #pragma unroll
       for (int j = 0; j < 16; ++j) hv[j] = s_hc[lane + 64 * j];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        cv[j] = s_hc[QD + lane + 64 * j];
-#pragma unroll
-        for (int c = 1; c < NC; ++c) cv[j] += s_hc[QD + c * ED + lane + 64 * j];
-      }
+      for (int j = 0; j < 8; ++j) cv[j] = s_hc[QD + lane + 64 * j];
 #pragma unroll
       for (int ri = 0; ri < 8; ++ri) {
         float s = 0.f;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) s += w[A_HA + ri * 16 + j] * hv[j];
+        for (int j = 0; j < 15; ++j) s += w[A_HA + ri * 16 + j] * hv[j];
+        s += s_w15[ri * NT + tid] * hv[15];
 #pragma unroll
         for (int j = 0; j < 8; ++j) s += wc[(ri * 8 + j) * 64] * cv[j];
         acc[ri] = s;
@@ -315,29 +386,41 @@ __device__ void att_role(const T2P& p, int a, float* sm) {
         for (int j = 0; j < 4; ++j) s += w[A_X2 + ri * 4 + j] * xv[j];
         g[ri] = wsum(s) + w[A_B + ri];
       }
-      // (the gate nonlinearities of the wave's units evaluated side by side on lanes 0-7 instead of one after the
-      // other measured slower: 12.6 against 12.4 us per step)
-      hh[0] = lstm_cell(g[0], g[1], g[2], g[3], &cc[0]);
-      hh[1] = lstm_cell(g[4], g[5], g[6], g[7], &cc[1]);
-      if (lane == 0) s_pub[2 * wave] = hh[0], s_pub[2 * wave + 1] = hh[1];
+      if (lane == 0) {
+        reinterpret_cast<float4*>(s_g)[2 * wave] = make_float4(g[0], g[1], g[2], g[3]);
+        reinterpret_cast<float4*>(s_g)[2 * wave + 1] = make_float4(g[4], g[5], g[6], g[7]);
+      }
+      T2_MARK(a == 0, 10);
     }
     __syncthreads();
-    if (wave == 0 && lane < 16) publish(Xc + X_HA, 16 * a + lane, done ? 0.f : s_pub[lane], done ? tag | DONE_BIT : tag);
+    T2_MARK(a == 0, 12);
+    // The cell updates of all sixteen units side by side on sixteen lanes of one wave: as one instruction stream
+    // instead of sixteen (two per wave, two waves per SIMD taking turns on the transcendental unit: 0.4 us for
+    // the first wave and 0.6 more until the last one reached the barrier).
+    if (wave == 0 && lane < 16) {
+      if (!done) {
+        const float4 gv = reinterpret_cast<const float4*>(s_g)[lane];
+        hh = lstm_cell(gv.x, gv.y, gv.z, gv.w, &cc);
+      }
+      publish(Xc + X_HA, 16 * a + lane, done ? 0.f : hh, done ? tag | DONE_BIT : tag);
+    }
     T2_MARK(a == 0, 9);
     if (done) break;
   }
-  if (lane == 0) {
-    const int u = 16 * a + 2 * wave;
-    if (p.st.h_a) p.st.h_a[u] = hh[0], p.st.h_a[u + 1] = hh[1];
-    if (p.st.h_a_alt) p.st.h_a_alt[u] = hh[0], p.st.h_a_alt[u + 1] = hh[1];
-    if (p.st.c_a) p.st.c_a[u] = cc[0], p.st.c_a[u + 1] = cc[1];
+  if (wave == 0 && lane < 16) {
+    const int u = 16 * a + lane;
+    if (p.st.h_a) p.st.h_a[u] = hh;
+    if (p.st.h_a_alt) p.st.h_a_alt[u] = hh;
+    if (p.st.c_a) p.st.c_a[u] = cc;
   }
 }
 
 // ------------------------------------------------------------------ decoder LSTM: 8 hidden units
 // TS = positions the team's attention roles are built for (128, 256 or NC * 256).  Lane l of every wave holds
-// positions l + 64 j: the alignment weights are formed per wave, with the operations and the order of summation
-// of normalise<TM> (NC == 1) / normalise_all<NC>, so they are the numbers the attention workgroups get.
+// positions l + 64 j.  Up to 256 positions every wave forms the alignment weights by itself (no barrier), with
+// the operations and the order of summation of normalise<TM>; long texts share the work over the workgroup
+// through normalise_all<NC> (sixteen sigmoids per lane and wave would cost more than its three barriers: 4.3 us
+// from the partial energies to h_d against 2.0).  Either way they are the numbers the attention workgroups get.
 template <int TM, int NC>
 __device__ void dec_role(const T2P& p, int d, float* sm) {
   constexpr int TS = NC == 1 ? TM : NC * 256, NJ = TS / 64;
@@ -347,14 +430,18 @@ __device__ void dec_role(const T2P& p, int d, float* sm) {
   float* s_hd = s_wh + LDS_W;       // [1024]
   float* s_ha = s_hd + DD;          // [1024]
   float* s_e4 = s_ha + QD;          // [4][TS] partial energies
-  float* s_pub = s_e4 + N_EN * TS;  // [8]
-  int* s_flag = reinterpret_cast<int*>(s_pub + 8);
+  float* s_al = s_e4 + N_EN * TS;   // [TS] alignment weights (long texts)
+  float* s_red = s_al + (NC == 1 ? 0 : TS);  // [16]
+  float* s_g = s_red + 16;          // [8 units][4] gate pre-activations
+  int* s_flag = reinterpret_cast<int*>(s_g + 32);
   const int len = min(max(p.len[0], 0), p.T);
   float w[NS_DEC], wm[4 * NJ];
   {
     const float* img = p.img_dec + ((size_t)d * NS_DEC) * NT + tid;
 #pragma unroll
     for (int s = 0; s < NS_DEC; ++s) w[s] = img[(size_t)s * NT];
+#pragma unroll
+    for (int s = D_B; s < NS_DEC; ++s) w[s] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(w[s])));
     const float* G = p.ctx_gates + (size_t)(8 * d + wave) * 4 * TS + lane;
 #pragma unroll
     for (int s = 0; s < 4 * NJ; ++s) wm[s] = G[(size_t)(s / NJ) * TS + 64 * (s % NJ)];
@@ -365,7 +452,7 @@ __device__ void dec_role(const T2P& p, int d, float* sm) {
   const bool softmax = p.norm == TTSX_NORM_SOFTMAX;
   __syncthreads();
   const float* wh = s_wh + (size_t)wave * 4 * 16 * 64 + lane;
-  float cc[1] = {0.f}, hh[1] = {0.f};
+  float cc = 0.f, hh = 0.f;  // lanes 0-7 of the first wave: the workgroup's eight units
   for (int t = 0; t < p.S; ++t) {
     const unsigned tag = (unsigned)t + 1u;
     u64* Xc = p.xch + (size_t)(t & 1) * X_PAR;
@@ -410,60 +497,57 @@ __device__ void dec_role(const T2P& p, int d, float* sm) {
       if (st & 2) break;
     }
     {
-      float v[NJ];
-      float m = 0.f;
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const int i = lane + 64 * j;
-        v[j] = ((s_e4[i] + s_e4[TS + i]) + (s_e4[2 * TS + i] + s_e4[3 * TS + i])) + vb;
-      }
-      if (softmax) {
-        float x = -INFINITY;
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) x = fmaxf(x, lane + 64 * j < len ? v[j] : -INFINITY);
-        m = wmax(x);
-      }
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) v[j] = lane + 64 * j < len ? (softmax ? expf(v[j] - m) : sigmoidf_(v[j])) : 0.f;
-      float sum;
+      float a[NJ];
       if constexpr (NC == 1) {
-        // normalise<TM>: wave j of the attention workgroup adds positions 64 j ... 64 j + 63; the wave sums in order
-        sum = wsum(v[0]);
+        float m = 0.f;
 #pragma unroll
-        for (int j = 1; j < NJ; ++j) sum += wsum(v[j]);
-      } else {
-        // normalise_all<NC>: thread tid adds its positions tid + 512 j, wave w = tid / 64 sums them; in wave order
-        static_assert(NJ % 8 == 0, "whole rounds of 512 positions");
-        sum = 0.f;
-#pragma unroll
-        for (int wv = 0; wv < 8; ++wv) {
-          float part = 0.f;
-#pragma unroll
-          for (int j = 0; j < NJ / 8; ++j) part += v[wv + 8 * j];
-          const float ws = wsum(part);
-          sum = wv == 0 ? ws : sum + ws;
+        for (int j = 0; j < NJ; ++j) {
+          const int i = lane + 64 * j;
+          a[j] = ((s_e4[i] + s_e4[TS + i]) + (s_e4[2 * TS + i] + s_e4[3 * TS + i])) + vb;
         }
+        if (softmax) {
+          float x = -INFINITY;
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) x = fmaxf(x, lane + 64 * j < len ? a[j] : -INFINITY);
+          m = wmax(x);
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) a[j] = lane + 64 * j < len ? (softmax ? expf(a[j] - m) : sigmoidf_(a[j])) : 0.f;
+        // normalise<TM>: wave j of the attention workgroup adds positions 64 j ... 64 j + 63; the wave sums in order
+        float sum = wsum(a[0]);
+#pragma unroll
+        for (int j = 1; j < NJ; ++j) sum += wsum(a[j]);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) a[j] = a[j] / sum;
+      } else {
+        normalise_all<NC>(s_e4, vb, len, p.norm, s_al, s_red);
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) a[j] = s_al[lane + 64 * j];
       }
       float g4[4];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         float s = acc[g];
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) s += wm[g * NJ + j] * (v[j] / sum);
+        for (int j = 0; j < NJ; ++j) s += wm[g * NJ + j] * a[j];
         g4[g] = wsum(s) + w[D_B + g];
       }
-      hh[0] = lstm_cell(g4[0], g4[1], g4[2], g4[3], &cc[0]);
-      if (lane == 0) s_pub[wave] = hh[0];
+      if (lane == 0) reinterpret_cast<float4*>(s_g)[wave] = make_float4(g4[0], g4[1], g4[2], g4[3]);
     }
     __syncthreads();
-    if (wave == 0 && lane < 8) publish(Xc + X_HD, 8 * d + lane, s_pub[lane], tag);
+    if (wave == 0 && lane < 8) {  // (the eight cell updates as one instruction stream, as in the attention LSTM)
+      const float4 gv = reinterpret_cast<const float4*>(s_g)[lane];
+      hh = lstm_cell(gv.x, gv.y, gv.z, gv.w, &cc);
+      publish(Xc + X_HD, 8 * d + lane, hh, tag);
+    }
     T2_MARK(d == 0, 34);
   }
-  if (lane == 0) {
-    const int u = 8 * d + wave;
-    if (p.st.h_d) p.st.h_d[u] = hh[0];
-    if (p.st.h_d_alt) p.st.h_d_alt[u] = hh[0];
-    if (p.st.c_d) p.st.c_d[u] = cc[0];
+  if (wave == 0 && lane < 8) {
+    const int u = 8 * d + lane;
+    if (p.st.h_d) p.st.h_d[u] = hh;
+    if (p.st.h_d_alt) p.st.h_d_alt[u] = hh;
+    if (p.st.c_d) p.st.c_d[u] = cc;
   }
 }
 
@@ -495,12 +579,13 @@ __device__ void proj_role(const T2P& p, int q, float* sm) {
     const unsigned tag = (unsigned)t + 1u;
     u64* Xc = p.xch + (size_t)(t & 1) * X_PAR;
     const u64* Xp = p.xch + (size_t)((t & 1) ^ 1) * X_PAR;
+    float xin[24];
     if (t > 0) {
-      // ---- the projection of step t - 1: frames, stop token, prenet layer 1 of the fed-back frame
+      // ---- the projection of step t - 1.  First what the chain waits for: prenet layer 1 of the fed-back frame
+      // (and, in its owner's wave, the stop token)
       if (fetch_span2<(NC * ED + DD) / NT>(Xp + X_CTX, NC * ED, Xp + X_HD, DD, tag - 1, s_in, p.abort_word, s_flag) & 1)
         return;
     T2_MARK(q == 0, 0);
-      float xin[24];
 #pragma unroll
       for (int j = 0; j < 16; ++j) xin[j] = s_in[NC * ED + lane + 64 * j];
 #pragma unroll
@@ -510,25 +595,20 @@ __device__ void proj_role(const T2P& p, int q, float* sm) {
         for (int c = 1; c < NC; ++c) cvj += s_in[c * ED + lane + 64 * j];
         xin[16 + j] = cvj, xctx[j] = cvj;
       }
-      float val[5];
+      float val[2];
 #pragma unroll
-      for (int rs = 0; rs < 5; ++rs) {
+      for (int rs = 0; rs < 2; ++rs) {
         float s = 0.f;
 #pragma unroll
         for (int j = 0; j < 24; ++j) s += w[P_ROW + rs * 24 + j] * xin[j];
         val[rs] = wsum(s) + w[P_B + rs];
       }
-      if (lane == 0) {
-        s_pub[2 * wave] = fmaxf(val[0], 0.f), s_pub[2 * wave + 1] = fmaxf(val[1], 0.f);
-        const size_t row0 = (size_t)(t - 1) * p.r * MEL;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const int m = q + 16 * (wave + 8 * i);
-          if (m < n_mel) p.mel[row0 + m] = val[2 + i];
-        }
-      }
+      if (lane == 0) s_pub[2 * wave] = fmaxf(val[0], 0.f), s_pub[2 * wave + 1] = fmaxf(val[1], 0.f);
       if (owner) {
-        const float s = sigmoidf_(val[4]);
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 24; ++j) s += w[P_ROW + 4 * 24 + j] * xin[j];
+        s = sigmoidf_(wsum(s) + w[P_B + 4]);
         if (lane == 0) p.stop[t - 1] = s;
         if (s > p.thr && n_stop == 0) n_stop = t;
       }
@@ -538,10 +618,28 @@ __device__ void proj_role(const T2P& p, int q, float* sm) {
     }
     const bool fin = t == p.S || (p.free_run && n_stop != 0);  // (the second term is the owner wave's knowledge)
     __syncthreads();
-    if (t == p.S) break;  // every workgroup knows the step limit
-    if (wave == 0 && lane < 16) publish(Xc + X_X1, 16 * q + lane, s_pub[lane], tag);
-    if (owner && lane == 0) publish(Xc + X_X1, PD, 0.f, fin ? tag | DONE_BIT : tag);
+    if (t < p.S) {
+      if (wave == 0 && lane < 16) publish(Xc + X_X1, 16 * q + lane, s_pub[lane], tag);
+      if (owner && lane == 0) publish(Xc + X_X1, PD, 0.f, fin ? tag | DONE_BIT : tag);
+    }
     T2_MARK(q == 0, 1);
+    if (t > 0) {
+      // ---- then, while x1 travels, the frame rows of step t - 1 (the inputs pass through an empty statement so
+      // that these sums are not formed ahead of the publication)
+#pragma unroll
+      for (int j = 0; j < 24; ++j) asm volatile("" : "+v"(xin[j]));
+      const size_t row0 = (size_t)(t - 1) * p.r * MEL;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 24; ++j) s += w[P_ROW + (2 + i) * 24 + j] * xin[j];
+        s = wsum(s) + w[P_B + 2 + i];
+        const int m = q + 16 * (wave + 8 * i);
+        if (lane == 0 && m < n_mel) p.mel[row0 + m] = s;
+      }
+    }
+    if (t == p.S) break;  // every workgroup knows the step limit
     // ---- prenet layer 2
     const int st = fetch_span<1>(Xc + X_X1, PD + 1, tag, s_x1, p.abort_word, s_flag);
     T2_MARK(q == 0, 2);
@@ -771,49 +869,6 @@ __device__ void ctx_role(const T2P& p, int c, float* sm) {
 }
 
 // ------------------------------------------------------------------ long texts: NC chunks of 256 positions
-// Alignment weights of ALL NC * 256 positions from the partial energies in LDS ([4][NC * 256]): every energy and
-// context workgroup of a long-text team runs exactly this, then uses its own chunk.  A thread holds positions
-// tid + 512 j.  Called by all threads; the caller synchronises before s_al is read.
-template <int NC>
-__device__ __forceinline__ void normalise_all(const float* s_e4, float vb, int len, int norm, float* s_al, float* s_red) {
-  constexpr int TS = NC * 256, NPT = TS / NT;
-  static_assert(TS % NT == 0, "two chunks per 512 threads");
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const bool softmax = norm == TTSX_NORM_SOFTMAX;
-  float en[NPT];
-#pragma unroll
-  for (int j = 0; j < NPT; ++j) {
-    const int i = tid + NT * j;
-    en[j] = ((s_e4[i] + s_e4[TS + i]) + (s_e4[2 * TS + i] + s_e4[3 * TS + i])) + vb;
-  }
-  float m = 0.f;
-  if (softmax) {
-    float x = -INFINITY;
-#pragma unroll
-    for (int j = 0; j < NPT; ++j) x = fmaxf(x, tid + NT * j < len ? en[j] : -INFINITY);
-    x = wmax(x);
-    if (lane == 0) s_red[wave] = x;
-    __syncthreads();
-    m = s_red[0];
-#pragma unroll
-    for (int i = 1; i < NT / 64; ++i) m = fmaxf(m, s_red[i]);
-  }
-  float v[NPT], part = 0.f;
-#pragma unroll
-  for (int j = 0; j < NPT; ++j) {
-    v[j] = tid + NT * j < len ? (softmax ? expf(en[j] - m) : sigmoidf_(en[j])) : 0.f;
-    part += v[j];
-  }
-  part = wsum(part);
-  if (lane == 0) s_red[8 + wave] = part;
-  __syncthreads();
-  float sum = s_red[8];
-#pragma unroll
-  for (int i = 1; i < NT / 64; ++i) sum += s_red[8 + i];
-#pragma unroll
-  for (int j = 0; j < NPT; ++j) s_al[tid + NT * j] = v[j] / sum;
-}
-
 // Energies of one chunk of 256 positions over 32 attention dimensions: workgroup ge = 4 * chunk + slice.
 template <int NC>
 __device__ void energy_long_role(const T2P& p, int ge, float* sm) {
@@ -1016,8 +1071,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   }
 }
 
-constexpr size_t LDS_ATT = (size_t)(LDS_W + PD + QD + NC_MAX * ED + 16 + 8) * sizeof(float);
-constexpr size_t LDS_DEC = (size_t)(LDS_W + DD + QD + N_EN * NC_MAX * 256 + 8 + 8) * sizeof(float);
+constexpr size_t LDS_ATT = (size_t)(LDS_W + PD + QD + NC_MAX * ED + 64 + 8 + 8 * NT) * sizeof(float);
+static_assert(LDS_ATT <= 160 * 1024, "an attention-LSTM workgroup's LDS");
+constexpr size_t LDS_DEC = (size_t)(LDS_W + DD + QD + (N_EN + 1) * NC_MAX * 256 + 16 + 32 + 8) * sizeof(float);
 static_assert(LDS_DEC <= 160 * 1024, "a decoder-LSTM workgroup's LDS");
 constexpr size_t LDS_EN = (size_t)(2 * LOCK * LOCF + 32 * LOCF + 32 + 2 * (TMAX + 32) + TMAX * (LOCF + 1) + QD + 32 +
                                    4 * TMAX + N_EN * TMAX + 8 + 8) * sizeof(float);
