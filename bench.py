@@ -55,11 +55,12 @@ GL_FLOPS_PER_FRAME = 121 * 2.5 * 2048 * 11           # 121 real FFTs of 2048 poi
 
 
 # One exchange between the workgroups of a persistent team (every workgroup publishes its words with one store,
-# every consumer polls each word once): measured 1.5 - 1.9 us at the team sizes used (tools/exchange_probe.hip:
-# 1.15 us bare at 32 workgroups / 256 words, 1.9 us at 256 workgroups / 1024 words; in-kernel timestamps of the
-# team kernels: tools/t2_team_timing.py).  The serial chain of a decoder step holds six of them.
-TEAM_EXCHANGE_US = 1.7
-TEAM_EXCHANGES_T2 = 6
+# every consumer polls each word once and hands it on through LDS): 1.2 us from the publishing store to the
+# consumers' barrier, the mean of the five on a Tacotron2 step in the kernel's own timestamps (0.9 - 1.5 us;
+# tools/t2_team_timing.py; tools/exchange_probe.hip: 1.15 us bare at 32 workgroups / 256 words).  The serial chain
+# of a Tacotron2 step holds five of them (x1 | x2 | h_a | partial energies | h_d), that of a Tacotron (v1) step six.
+TEAM_EXCHANGE_US = 1.2
+TEAM_EXCHANGES_T2 = 5
 TEAM_EXCHANGES_T1 = 6
 
 
