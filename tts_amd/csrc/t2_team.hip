@@ -52,12 +52,12 @@ constexpr int LOCF = 32, LOCK = 31, LPAD = 15, TMAX = 256;  // (attention roles 
 constexpr int N_ATT = 64, N_DEC = 128, N_PROJ = 16, N_EN = 4;  // (and as many context workgroups as energy workgroups)
 constexpr int G_DEC0 = N_ATT, G_PROJ0 = G_DEC0 + N_DEC, G_EN0 = G_PROJ0 + N_PROJ;
 constexpr unsigned DONE_BIT = 0x80000000u;
-constexpr int PROJ_K = DD + ED;
+constexpr int PROJ_K = DD + ED, PROJ_ROWS_MAX = 2 * MEL + 16 + PD;
 
 // register images: slot s of thread tid of workgroup g of a role at img[(g * NS + s) * NT + tid]
 constexpr int A_X2 = 0, A_HA = 32, A_B = 160, NS_ATT = 168;   // row ri = 4 * unit_in_wave + gate
 constexpr int D_HA = 0, D_B = 64, NS_DEC = 68;   // row = gate
-constexpr int P_ROW = 0, P_B = 120, P_W2 = 125, P_B2 = 133, NS_PROJ = 135;
+constexpr int P_ROW = 0, P_B = 80, P_W2 = 85, P_B2 = 93, NS_PROJ = 95;  // (rows over h_d only: sixteen slots each)
 constexpr int NS_EN = 64;
 constexpr int LDS_W = 32768;  // floats of weights in the LDS of an LSTM workgroup
 
@@ -70,6 +70,7 @@ constexpr int X_HA = 0, X_CTX = X_HA + QD, X_HD = X_CTX + NC_MAX * ED, X_X1 = X_
 struct T2P {
   const float *img_att, *lds_att, *img_dec, *lds_dec, *img_proj, *img_en;
   const float* ctx_gates;  // [1024 units][4 gates][TS positions]: decoder-LSTM context columns x encoder outputs
+  const float* ctx_proj;   // [80 r + 272 rows][TS]: the projection rows' context columns x encoder outputs
   const float *conv_t /* [62][32] */, *loc_dense /* [128][32] */, *v_w, *v_b, *b1f;
   const float *enc, *P;
   const int32_t* len;
@@ -297,6 +298,47 @@ __device__ __forceinline__ void normalise_all(const float* s_e4, float vb, int l
   for (int j = 0; j < NPT; ++j) s_al[tid + NT * j] = v[j] / sum;
 }
 
+// Row of the composed projection matrix behind slot rs of wave `wave` of projection workgroup q (or -1): the composed
+// prenet-1 rows 16 q + 2 w, + 1 (slots 0, 1), the mel rows q + 16 (w + 8 i) below 80 r (slots 2, 3), and - wave 7 of
+// the last workgroup - the composed stop row (slot 4).
+__host__ __device__ __forceinline__ int proj_src_row(int rs, int q, int wave, int n_mel) {
+  if (rs < 2) return n_mel + 16 + 16 * q + 2 * wave + rs;
+  if (rs < 4) {
+    const int m = q + 16 * (wave + 8 * (rs - 2));
+    return m < n_mel ? m : -1;
+  }
+  return q == N_PROJ - 1 && wave == 7 ? n_mel : -1;
+}
+
+// Alignment weights of positions lane + 64 j (j < TS / 64) formed by ONE wave from the partial energies in LDS
+// ([4][TS]), with the operations and the order of summation of normalise<TS>: wave j of an attention workgroup adds
+// positions 64 j ... 64 j + 63, and the wave sums are added in order.  For consumers of the alignment that are not
+// attention workgroups (up to 256 positions: no barrier).
+template <int TS>
+__device__ __forceinline__ void wave_alignments(const float* s_e4, float vb, int len, bool softmax, float* a) {
+  constexpr int NJ = TS / 64;
+  const int lane = threadIdx.x & 63;
+  float m = 0.f;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int i = lane + 64 * j;
+    a[j] = ((s_e4[i] + s_e4[TS + i]) + (s_e4[2 * TS + i] + s_e4[3 * TS + i])) + vb;
+  }
+  if (softmax) {
+    float x = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) x = fmaxf(x, lane + 64 * j < len ? a[j] : -INFINITY);
+    m = wmax(x);
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) a[j] = lane + 64 * j < len ? (softmax ? expf(a[j] - m) : sigmoidf_(a[j])) : 0.f;
+  float sum = wsum(a[0]);
+#pragma unroll
+  for (int j = 1; j < NJ; ++j) sum += wsum(a[j]);
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) a[j] = a[j] / sum;
+}
+
 // ------------------------------------------------------------------ attention LSTM: 16 hidden units
 template <int NC>
 __device__ void att_role(const T2P& p, int a, float* sm) {
@@ -499,26 +541,7 @@ __device__ void dec_role(const T2P& p, int d, float* sm) {
     {
       float a[NJ];
       if constexpr (NC == 1) {
-        float m = 0.f;
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-          const int i = lane + 64 * j;
-          a[j] = ((s_e4[i] + s_e4[TS + i]) + (s_e4[2 * TS + i] + s_e4[3 * TS + i])) + vb;
-        }
-        if (softmax) {
-          float x = -INFINITY;
-#pragma unroll
-          for (int j = 0; j < NJ; ++j) x = fmaxf(x, lane + 64 * j < len ? a[j] : -INFINITY);
-          m = wmax(x);
-        }
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) a[j] = lane + 64 * j < len ? (softmax ? expf(a[j] - m) : sigmoidf_(a[j])) : 0.f;
-        // normalise<TM>: wave j of the attention workgroup adds positions 64 j ... 64 j + 63; the wave sums in order
-        float sum = wsum(a[0]);
-#pragma unroll
-        for (int j = 1; j < NJ; ++j) sum += wsum(a[j]);
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) a[j] = a[j] / sum;
+        wave_alignments<TS>(s_e4, vb, len, softmax, a);
       } else {
         normalise_all<NC>(s_e4, vb, len, p.norm, s_al, s_red);
         __syncthreads();
@@ -555,59 +578,91 @@ __device__ void dec_role(const T2P& p, int d, float* sm) {
 // Wave w of workgroup q owns: the composed prenet-1 rows 16 q + 2 w, + 1 (slots 0, 1), the mel rows
 // q + 16 (w + 8 i), i = 0, 1 (slots 2, 3; below 80 r), and - wave 7 of workgroup 15 - the composed stop row (slot 4);
 // prenet-2 rows 16 q + 2 w, + 1.
-template <int NC>
+// The rows' columns over the context are held as their products with the utterance's encoder outputs, like the
+// decoder LSTM's (ctx_proj): the workgroup forms the alignment weights of step t - 1 from the partial energies while
+// the decoder LSTM is still at work, and what it waits for on the chain is h_d alone.
+template <int TM, int NC>
 __device__ void proj_role(const T2P& p, int q, float* sm) {
+  constexpr int TS = NC == 1 ? TM : NC * 256, NJ = TS / 64;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  float* s_in = sm;                 // [NC][512] partial contexts, [1024] h_d
-  float* s_x1 = s_in + NC * ED + DD;  // [257]
+  float* s_hd = sm;                 // [1024] h_d; after the run: [NC][512] the last context
+  float* s_e4 = s_hd + (NC * ED > DD ? NC * ED : DD);  // [4][TS] partial energies
+  float* s_al = s_e4 + N_EN * TS;   // [TS] alignment weights (long texts)
+  float* s_red = s_al + (NC == 1 ? 0 : TS);  // [16]
+  float* s_x1 = s_red + 16;         // [257]
   float* s_pub = s_x1 + X_X1_N;     // [16] x1 slice, [16] x2 slice
   int* s_flag = reinterpret_cast<int*>(s_pub + 32);
-  float w[NS_PROJ];
+  const bool owner = q == N_PROJ - 1 && wave == 7;  // of the stop row
+  const int n_mel = MEL * p.r;
+  const int len = min(max(p.len[0], 0), p.T);
+  float w[NS_PROJ], wg[5 * NJ];
   {
     const float* img = p.img_proj + ((size_t)q * NS_PROJ) * NT + tid;
 #pragma unroll
     for (int s = 0; s < NS_PROJ; ++s) w[s] = img[(size_t)s * NT];
+#pragma unroll
+    for (int s = P_B; s < NS_PROJ; ++s)
+      if (s < P_W2 || s >= P_B2) w[s] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(w[s])));
+#pragma unroll
+    for (int rs = 0; rs < 5; ++rs) {
+      const int row = proj_src_row(rs, q, wave, n_mel);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) wg[rs * NJ + j] = row >= 0 ? p.ctx_proj[(size_t)row * TS + lane + 64 * j] : 0.f;
+    }
   }
   if (tid == 0) *s_flag = 0;
+  const float vb = p.v_b[0];
+  const bool softmax = p.norm == TTSX_NORM_SOFTMAX;
   __syncthreads();
-  const bool owner = q == N_PROJ - 1 && wave == 7;  // of the stop row
-  const int n_mel = MEL * p.r;
   int n_stop = 0;  // 1-based step of the first stop token above the threshold (owner wave)
-  float xctx[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // the context of the last step projected
-  for (int t = 0;; ++t) {
+  int t = 0;
+  for (;; ++t) {
     const unsigned tag = (unsigned)t + 1u;
     u64* Xc = p.xch + (size_t)(t & 1) * X_PAR;
     const u64* Xp = p.xch + (size_t)((t & 1) ^ 1) * X_PAR;
-    float xin[24];
+    float xin[16], cs[5];
     if (t > 0) {
-      // ---- the projection of step t - 1.  First what the chain waits for: prenet layer 1 of the fed-back frame
-      // (and, in its owner's wave, the stop token)
-      if (fetch_span2<(NC * ED + DD) / NT>(Xp + X_CTX, NC * ED, Xp + X_HD, DD, tag - 1, s_in, p.abort_word, s_flag) & 1)
-        return;
+      // ---- the projection of step t - 1.  Off the chain: the context's share of every row from the partial
+      // energies (no end-of-run mark can arrive here: the marks start from this role)
+      if (fetch_span<N_EN * TS / NT>(Xp + X_EP, N_EN * TS, tag - 1, s_e4, p.abort_word, s_flag) & 1) return;
+      {
+        float a[NJ];
+        if constexpr (NC == 1) {
+          wave_alignments<TS>(s_e4, vb, len, softmax, a);
+        } else {
+          normalise_all<NC>(s_e4, vb, len, p.norm, s_al, s_red);
+          __syncthreads();
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) a[j] = s_al[lane + 64 * j];
+        }
+#pragma unroll
+        for (int rs = 0; rs < 5; ++rs) {
+          float c = 0.f;
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) c += wg[rs * NJ + j] * a[j];
+          cs[rs] = c;
+          asm volatile("" : "+v"(cs[rs])::"memory");  // formed here, not behind the next wait
+        }
+      }
+      // ---- on the chain: h_d, then prenet layer 1 of the fed-back frame (and, in its owner's wave, the stop token)
+      if (fetch_span<DD / NT>(Xp + X_HD, DD, tag - 1, s_hd, p.abort_word, s_flag) & 1) return;
     T2_MARK(q == 0, 0);
 #pragma unroll
-      for (int j = 0; j < 16; ++j) xin[j] = s_in[NC * ED + lane + 64 * j];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        float cvj = s_in[lane + 64 * j];
-#pragma unroll
-        for (int c = 1; c < NC; ++c) cvj += s_in[c * ED + lane + 64 * j];
-        xin[16 + j] = cvj, xctx[j] = cvj;
-      }
+      for (int j = 0; j < 16; ++j) xin[j] = s_hd[lane + 64 * j];
       float val[2];
 #pragma unroll
       for (int rs = 0; rs < 2; ++rs) {
-        float s = 0.f;
+        float s = cs[rs];
 #pragma unroll
-        for (int j = 0; j < 24; ++j) s += w[P_ROW + rs * 24 + j] * xin[j];
+        for (int j = 0; j < 16; ++j) s += w[P_ROW + rs * 16 + j] * xin[j];
         val[rs] = wsum(s) + w[P_B + rs];
       }
       if (lane == 0) s_pub[2 * wave] = fmaxf(val[0], 0.f), s_pub[2 * wave + 1] = fmaxf(val[1], 0.f);
       if (owner) {
-        float s = 0.f;
+        float s = cs[4];
 #pragma unroll
-        for (int j = 0; j < 24; ++j) s += w[P_ROW + 4 * 24 + j] * xin[j];
+        for (int j = 0; j < 16; ++j) s += w[P_ROW + 4 * 16 + j] * xin[j];
         s = sigmoidf_(wsum(s) + w[P_B + 4]);
         if (lane == 0) p.stop[t - 1] = s;
         if (s > p.thr && n_stop == 0) n_stop = t;
@@ -627,13 +682,13 @@ __device__ void proj_role(const T2P& p, int q, float* sm) {
       // ---- then, while x1 travels, the frame rows of step t - 1 (the inputs pass through an empty statement so
       // that these sums are not formed ahead of the publication)
 #pragma unroll
-      for (int j = 0; j < 24; ++j) asm volatile("" : "+v"(xin[j]));
+      for (int j = 0; j < 16; ++j) asm volatile("" : "+v"(xin[j]));
       const size_t row0 = (size_t)(t - 1) * p.r * MEL;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        float s = 0.f;
+        float s = cs[2 + i];
 #pragma unroll
-        for (int j = 0; j < 24; ++j) s += w[P_ROW + (2 + i) * 24 + j] * xin[j];
+        for (int j = 0; j < 16; ++j) s += w[P_ROW + (2 + i) * 16 + j] * xin[j];
         s = wsum(s) + w[P_B + 2 + i];
         const int m = q + 16 * (wave + 8 * i);
         if (lane == 0 && m < n_mel) p.mel[row0 + m] = s;
@@ -663,13 +718,20 @@ __device__ void proj_role(const T2P& p, int q, float* sm) {
     T2_MARK(q == 0, 3);
     if (done) break;
   }
-  // what the next step would have been fed, the step count
+  // what the next step would have been fed, the step count, and the context of the last step (t >= 1 here; the
+  // context workgroups published it with the tag of that step, and nothing has overwritten it since)
   if (p.st.x1 && wave == 0 && lane < 16) p.st.x1[16 * q + lane] = s_pub[lane];
-  if (p.st.ctx && q == 0 && wave == 0) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) p.st.ctx[lane + 64 * j] = xctx[j];
-  }
   if (owner && lane == 0) p.n_steps[0] = n_stop;
+  if (p.st.ctx && q == 0) {
+    const u64* Xl = p.xch + (size_t)((t - 1) & 1) * X_PAR;
+    if (fetch_span<NC * ED / NT>(Xl + X_CTX, NC * ED, (unsigned)t, s_hd, p.abort_word, s_flag) & 1) return;
+    if (tid < ED) {
+      float c = s_hd[tid];
+#pragma unroll
+      for (int k = 1; k < NC; ++k) c += s_hd[k * ED + tid];
+      p.st.ctx[tid] = c;
+    }
+  }
 }
 
 // ------------------------------------------------------------------ energies: 32 attention dimensions
@@ -1061,7 +1123,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   constexpr int g_ctx0 = G_EN0 + N_EN * NC;
   if (g < G_DEC0) att_role<NC>(p, g, sm);
   else if (g < G_PROJ0) dec_role<TM, NC>(p, g - G_DEC0, sm);
-  else if (g < G_EN0) proj_role<NC>(p, g - G_PROJ0, sm);
+  else if (g < G_EN0) proj_role<TM, NC>(p, g - G_PROJ0, sm);
   else if constexpr (NC == 1) {
     if (g < g_ctx0) energy_role<TM>(p, g - G_EN0, sm);
     else ctx_role<TM>(p, g - g_ctx0, sm);
@@ -1151,18 +1213,10 @@ __global__ void pack_proj_kernel(float* __restrict__ img, const float* __restric
   if (i >= (size_t)N_PROJ * NS_PROJ * NT) return;
   const int tid = (int)(i % NT), s = (int)((i / NT) % NS_PROJ), q = (int)(i / ((size_t)NT * NS_PROJ));
   const int lane = tid & 63, wave = tid >> 6, n_mel = MEL * r;
-  // source row of slot rs (or -1)
-  auto src_row = [&](int rs) {
-    if (rs < 2) return n_mel + 16 + 16 * q + 2 * wave + rs;
-    if (rs < 4) {
-      const int m = q + 16 * (wave + 8 * (rs - 2));
-      return m < n_mel ? m : -1;
-    }
-    return q == N_PROJ - 1 && wave == 7 ? n_mel : -1;
-  };
+  auto src_row = [&](int rs) { return proj_src_row(rs, q, wave, n_mel); };
   float v = 0.f;
   if (s < P_B) {
-    const int row = src_row(s / 24), j = s % 24;
+    const int row = src_row(s / 16), j = s % 16;  // (the columns over h_d; those over the context: ctx_proj)
     if (row >= 0) v = rows_w[(size_t)row * PROJ_K + lane + 64 * j];
   } else if (s < P_W2) {
     const int row = src_row(s - P_B);
@@ -1176,17 +1230,20 @@ __global__ void pack_proj_kernel(float* __restrict__ img, const float* __restric
   img[i] = v;
 }
 
-// G[row][p] = W_c[row] . enc[p] for the 4096 rows (unit, gate) of the decoder LSTM's context columns and the TS
-// positions the team is built for (zero beyond the utterance's own length): once per run, before the team starts.
+// G[row][p] = W_c[row] . enc[p] for `rows` rows of context columns (16 n; row stride ldw floats) - the 4096 rows
+// (unit, gate) of the decoder LSTM, the rows of the composed projection - and the TS positions the team is built
+// for (zero beyond the utterance's own length): once per run, before the team starts.
 // A wave forms 16 rows x 64 positions on v_mfma_f32_16x16x4_f32; lane l supplies row / position l & 15 and, for
 // the four instructions of a 16-byte load, K index 16 i + 4 (l >> 4) + s on both sides.
 __global__ __launch_bounds__(256) void ctx_gates_kernel(const float* __restrict__ Wc, const float* __restrict__ enc,
-                                                         const int32_t* __restrict__ len_p, int T, int TS, float* __restrict__ G) {
+                                                         const int32_t* __restrict__ len_p, int T, int TS, int rows, int ldw,
+                                                         float* __restrict__ G) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int rb = blockIdx.x * 4 + wave, pb = blockIdx.y;
+  if (16 * rb >= rows) return;
   const int r = lane & 15, kq = lane >> 4;
   const int len = min(max(len_p[0], 0), T);
-  const f32x4* A = reinterpret_cast<const f32x4*>(Wc + (size_t)(16 * rb + r) * ED) + kq;
+  const f32x4* A = reinterpret_cast<const f32x4*>(Wc + (size_t)(16 * rb + r) * ldw) + kq;
   const f32x4* Bp[4];
   bool in[4];
 #pragma unroll
@@ -1221,6 +1278,8 @@ __global__ __launch_bounds__(256) void ctx_gates_kernel(const float* __restrict_
 struct t2_team {
   float *img_att, *lds_att, *img_dec, *lds_dec, *img_proj, *img_en, *conv_t, *loc_dense;
   float *ctx_cols, *ctx_gates;  // [4096][512] context columns of the decoder LSTM; their products with one utterance
+  float *proj_cols, *ctx_proj;  // [80 r + 272][1536] the composed projection rows (own copy); the same products
+  int proj_rows;
   float *v_w, *v_b, *b1f, *a2f, *b2f;  // own copies
   int proj_r;
   u64* xch;
@@ -1261,6 +1320,8 @@ int t2_team_create(const T2TeamWeights* w, hipStream_t st, t2_team** out) {
   TTSX_HIP(alloc(&t->loc_dense, (size_t)AD * LOCF));
   TTSX_HIP(alloc(&t->ctx_cols, (size_t)4 * DD * ED));
   TTSX_HIP(alloc(&t->ctx_gates, (size_t)4 * DD * NC_MAX * 256));
+  TTSX_HIP(alloc(&t->proj_cols, (size_t)PROJ_ROWS_MAX * PROJ_K));
+  TTSX_HIP(alloc(&t->ctx_proj, (size_t)PROJ_ROWS_MAX * NC_MAX * 256));
   TTSX_HIP(hipMalloc(reinterpret_cast<void**>(&t->xch), sizeof(u64) * 2 * X_PAR));
   TTSX_HIP(hipMalloc(reinterpret_cast<void**>(&t->abort_word), sizeof(int)));
   int rc;
@@ -1284,7 +1345,7 @@ int t2_team_create(const T2TeamWeights* w, hipStream_t st, t2_team** out) {
 void t2_team_destroy(t2_team* t) {
   if (!t) return;
   float* bufs[] = {t->img_att, t->lds_att, t->img_dec, t->lds_dec, t->img_proj, t->img_en, t->conv_t,
-                   t->loc_dense, t->ctx_cols, t->ctx_gates, t->v_w, t->v_b, t->b1f, t->a2f, t->b2f};
+                   t->loc_dense, t->ctx_cols, t->ctx_gates, t->proj_cols, t->ctx_proj, t->v_w, t->v_b, t->b1f, t->a2f, t->b2f};
   for (float* b : bufs)
     if (b) (void)hipFree(b);
   if (t->xch) (void)hipFree(t->xch);
@@ -1299,6 +1360,10 @@ int t2_team_set_proj(t2_team* t, const float* rows_w, const float* rows_b, int r
   const size_t n = (size_t)N_PROJ * NS_PROJ * NT;
   pack_proj_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(t->img_proj, rows_w, rows_b, t->a2f, t->b2f, r);
   TTSX_LAUNCH_CHECK();
+  t->proj_rows = MEL * r + 16 + PD;  // frames, the stop row and padding, prenet layer 1
+  static_assert((MEL + 16 + PD) % 16 == 0 && (2 * MEL + 16 + PD) % 16 == 0 && 2 * MEL + 16 + PD <= PROJ_ROWS_MAX,
+                "whole 16-row blocks of the composed projection");
+  TTSX_HIP(hipMemcpyAsync(t->proj_cols, rows_w, sizeof(float) * (size_t)t->proj_rows * PROJ_K, hipMemcpyDeviceToDevice, st));
   t->proj_r = r;
   return TTSX_OK;
 }
@@ -1327,7 +1392,7 @@ int t2_team_run(t2_team* t, const float* enc, const float* P, const int32_t* len
   p.img_att = t->img_att, p.lds_att = t->lds_att, p.img_dec = t->img_dec, p.lds_dec = t->lds_dec;
   p.img_proj = t->img_proj, p.img_en = t->img_en, p.conv_t = t->conv_t, p.loc_dense = t->loc_dense;
   p.v_w = t->v_w, p.v_b = t->v_b, p.b1f = t->b1f, p.enc = enc, p.P = P, p.len = len, p.xch = t->xch;
-  p.ctx_gates = t->ctx_gates;
+  p.ctx_gates = t->ctx_gates, p.ctx_proj = t->ctx_proj;
   p.abort_word = t->abort_word, p.mel = mel, p.align = align, p.stop = stop, p.n_steps = n_steps;
   if (state_out) p.st = *state_out;
   p.T = T, p.r = r, p.S = max_steps, p.free_run = fixed_steps ? 0 : 1, p.norm = norm, p.thr = stop_threshold;
@@ -1338,7 +1403,10 @@ int t2_team_run(t2_team* t, const float* enc, const float* P, const int32_t* len
   // rocprofv3's kernel trace crashes at exit in a process that has made one.)
   const int grid = G_EN0 + 2 * N_EN * (T <= 256 ? 1 : NC_MAX);
   const int TS = T <= 128 ? 128 : T <= 256 ? 256 : NC_MAX * 256;
-  ctx_gates_kernel<<<dim3(4 * DD / 64, TS / 64), 256, 0, st>>>(t->ctx_cols, enc, len, T, TS, t->ctx_gates);
+  ctx_gates_kernel<<<dim3(4 * DD / 64, TS / 64), 256, 0, st>>>(t->ctx_cols, enc, len, T, TS, 4 * DD, ED, t->ctx_gates);
+  TTSX_LAUNCH_CHECK();
+  ctx_gates_kernel<<<dim3((t->proj_rows + 63) / 64, TS / 64), 256, 0, st>>>(t->proj_cols + DD, enc, len, T, TS, t->proj_rows,
+                                                                            PROJ_K, t->ctx_proj);
   TTSX_LAUNCH_CHECK();
   if (T <= 128) t2_team_kernel<128, 1><<<grid, NT, TEAM_LDS, st>>>(p);
   else if (T <= 256) t2_team_kernel<256, 1><<<grid, NT, TEAM_LDS, st>>>(p);
