@@ -29,15 +29,17 @@ lib.ttsx_debug_team_timing.restype = ctypes.c_int
 assert lib.ttsx_debug_team_timing(out) == 0
 t = list(out)
 row = ["frames arrive + stop rule", "prenet 1 published", "x1 arrives", "prenet 2", "attention GRU + query share",
-       "h_att + context arrive", "GRU 1 published", "d1 arrives", "GRU 2 published", "d2 arrives", "frames published"]
+       "h_att + alignment arrive", "GRU 1 published", "d1 arrives", "GRU 2 published", "d2 arrives", "frames published"]
 print("row workgroup 0 (us since the top of step 50):")
 for i, n in enumerate(row):
     print("  %-32s +%.2f  (at %.2f)" % (n, (t[i + 1] - t[i]) / 100.0, (t[i + 1] - t[0]) / 100.0))
-att = ["conv + location linear", "query shares arrive", "energies", "normalise", "context published", "d2 + frames arrive"]
-print("attention workgroup (us relative to the row workgroup's step top):")
-for i, n in enumerate(att):
-    print("  %-32s +%.2f  (at %.2f)" % (n, (t[17 + i] - t[16 + i]) / 100.0, (t[17 + i] - t[0]) / 100.0))
-print("  loop top at %.2f" % ((t[16] - t[0]) / 100.0))
+att = [(17, "loop top"), (18, "query shares arrive"), (19, "energies"), (21, "sigmoids published"),
+       (20, "all sigmoids seen, alignment state updated"), (16, "conv + location linear"), (22, "d2 + frames arrive")]
+print("attention workgroup 0 (us relative to the row workgroup's step top):")
+prev = t[17]
+for i, n in att:
+    print("  %-44s +%.2f  (at %.2f)" % (n, (t[i] - prev) / 100.0, (t[i] - t[0]) / 100.0))
+    prev = t[i]
 pub = [(t[64 + g] - t[0]) / 100.0 for g in range(32)]
 got = [(t[128 + g] - t[0]) / 100.0 for g in range(32)]
 bar = [(t[192 + g] - t[0]) / 100.0 for g in range(32)]

@@ -28,7 +28,7 @@
 // recurrent columns of both LSTMs, the location features) is evaluated while the chain is elsewhere.
 // The context is off that chain: it is a weighted sum of encoder outputs, ctx = sum_p a[p] enc[p], so what the
 // decoder LSTM needs of it is W_c ctx = sum_p a[p] (W_c enc[p]).  The products G[row][p] = W_c[row] . enc[p] are
-// formed once per utterance (ctx_gates_kernel) and held in registers; a decoder-LSTM workgroup takes the partial
+// formed once per utterance (ctx_products_kernel) and held in registers; a decoder-LSTM workgroup takes the partial
 // energies themselves, normalises them like every attention workgroup does (same operations, same order) and
 // adds sum_p a[p] G[row][p] - it never waits for the context workgroups, whose output goes to the projection and
 // to the next step's attention LSTM, both of which need it later than the decoder LSTM did.
@@ -40,6 +40,7 @@
 #include <vector>
 
 #include "common.h"
+#include "ctx_products.h"
 #include "t2_team.h"
 
 namespace {
@@ -1230,49 +1231,6 @@ __global__ void pack_proj_kernel(float* __restrict__ img, const float* __restric
   img[i] = v;
 }
 
-// G[row][p] = W_c[row] . enc[p] for `rows` rows of context columns (16 n; row stride ldw floats) - the 4096 rows
-// (unit, gate) of the decoder LSTM, the rows of the composed projection - and the TS positions the team is built
-// for (zero beyond the utterance's own length): once per run, before the team starts.
-// A wave forms 16 rows x 64 positions on v_mfma_f32_16x16x4_f32; lane l supplies row / position l & 15 and, for
-// the four instructions of a 16-byte load, K index 16 i + 4 (l >> 4) + s on both sides.
-__global__ __launch_bounds__(256) void ctx_gates_kernel(const float* __restrict__ Wc, const float* __restrict__ enc,
-                                                         const int32_t* __restrict__ len_p, int T, int TS, int rows, int ldw,
-                                                         float* __restrict__ G) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int rb = blockIdx.x * 4 + wave, pb = blockIdx.y;
-  if (16 * rb >= rows) return;
-  const int r = lane & 15, kq = lane >> 4;
-  const int len = min(max(len_p[0], 0), T);
-  const f32x4* A = reinterpret_cast<const f32x4*>(Wc + (size_t)(16 * rb + r) * ldw) + kq;
-  const f32x4* Bp[4];
-  bool in[4];
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    const int pos = 64 * pb + 16 * c + r;
-    in[c] = pos < len;
-    Bp[c] = reinterpret_cast<const f32x4*>(enc + (size_t)(in[c] ? pos : 0) * ED) + kq;
-  }
-  f32x4 acc[4];
-#pragma unroll
-  for (int c = 0; c < 4; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-  for (int i = 0; i < ED / 16; ++i) {
-    const f32x4 a = A[4 * i];
-    f32x4 b[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) b[c] = Bp[c][4 * i];
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[c][s], acc[c], 0, 0, 0);
-  }
-#pragma unroll
-  for (int c = 0; c < 4; ++c)
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      G[(size_t)(16 * rb + 4 * kq + i) * TS + 64 * pb + 16 * c + r] = in[c] ? acc[c][i] : 0.f;
-}
-
 }  // namespace
 
 struct t2_team {
@@ -1403,10 +1361,10 @@ int t2_team_run(t2_team* t, const float* enc, const float* P, const int32_t* len
   // rocprofv3's kernel trace crashes at exit in a process that has made one.)
   const int grid = G_EN0 + 2 * N_EN * (T <= 256 ? 1 : NC_MAX);
   const int TS = T <= 128 ? 128 : T <= 256 ? 256 : NC_MAX * 256;
-  ctx_gates_kernel<<<dim3(4 * DD / 64, TS / 64), 256, 0, st>>>(t->ctx_cols, enc, len, T, TS, 4 * DD, ED, t->ctx_gates);
+  ctx_products_kernel<ED><<<dim3(4 * DD / 64, TS / 64, 1), 256, 0, st>>>(t->ctx_cols, 4 * DD, ED, enc, len, 0, T, TS, t->ctx_gates);
   TTSX_LAUNCH_CHECK();
-  ctx_gates_kernel<<<dim3((t->proj_rows + 63) / 64, TS / 64), 256, 0, st>>>(t->proj_cols + DD, enc, len, T, TS, t->proj_rows,
-                                                                            PROJ_K, t->ctx_proj);
+  ctx_products_kernel<ED><<<dim3((t->proj_rows + 63) / 64, TS / 64, 1), 256, 0, st>>>(t->proj_cols + DD, t->proj_rows, PROJ_K, enc,
+                                                                                      len, 0, T, TS, t->ctx_proj);
   TTSX_LAUNCH_CHECK();
   if (T <= 128) t2_team_kernel<128, 1><<<grid, NT, TEAM_LDS, st>>>(p);
   else if (T <= 256) t2_team_kernel<256, 1><<<grid, NT, TEAM_LDS, st>>>(p);
