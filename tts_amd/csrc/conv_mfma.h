@@ -92,31 +92,34 @@ static __device__ __forceinline__ void store_tile(const ConvP& p, int cb, const 
   }
 }
 
-// Block = 4 waves as 2 (Cout) x 2 (frames); each wave owns a 64 x 64 output tile held as
-// 2 x 2 accumulators of 32 x 32.  Block tile: 128 channels x 128 frames.
+// Block = 4 waves as 2 (Cout) x 2 (frames); each wave owns a 64 x (32 NJ) output tile held as
+// 2 x NJ accumulators of 32 x 32.  Block tile: 128 channels x 128 frames (NJ = 2), or x 64 frames (NJ = 1) for
+// problems whose 128-frame tiles would leave every SIMD with a single wave: one wave cannot cover the latency of
+// its own operand loads (55 % of the matrix rate measured on 256 tiles, K = 2560).
+template <int NJ>
 static __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvP p) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int wm = wave >> 1, wn = wave & 1;
   const int half = lane >> 5, l31 = lane & 31;
   const int cb0 = blockIdx.y * 4 + wm * 2;           // first 32-row block of this wave
   const int ncb = ceil_div(p.Cout, 32);
-  const long n0 = (long)blockIdx.x * 128 + wn * 64;  // first frame column of this wave
+  const long n0 = (long)blockIdx.x * (64 * NJ) + wn * (32 * NJ);  // first frame column of this wave
 
   // per-lane frame coordinates of the two column tiles
-  int bb[2], ff[2], nf[2];
+  int bb[NJ], ff[NJ], nf[NJ];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
+  for (int j = 0; j < NJ; ++j) {
     const long n = n0 + j * 32 + l31;
     bb[j] = (int)(n / p.F);
     ff[j] = (int)(n % p.F);
     nf[j] = bb[j] < p.B ? (p.n_frames ? min(max(p.n_frames[bb[j]], 0), p.F) : p.F) : 0;   // (lengths clamped to 0..F)
   }
 
-  f32x16 acc[2][2];
+  f32x16 acc[2][NJ];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
@@ -125,12 +128,13 @@ static __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvP p) {
   const float4* W1 = reinterpret_cast<const float4*>(p.wp) + (size_t)(has_cb[1] ? cb0 + 1 : 0) * p.NC * 64 + lane;
   const int chunks_per_tap = p.Cin / 8;
   // (columns past the last utterance read utterance B-1 and are masked: nf = 0)
-  const float* xbase[2] = {p.x + (size_t)min(bb[0], p.B - 1) * p.F * p.x_pitch + 4 * half,
-                           p.x + (size_t)min(bb[1], p.B - 1) * p.F * p.x_pitch + 4 * half};
+  const float* xbase[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) xbase[j] = p.x + (size_t)min(bb[j], p.B - 1) * p.F * p.x_pitch + 4 * half;
 
   // operands of K chunk c (8 wide): two weight fragments, two activation fragments (zero outside the utterance)
   struct Frag {
-    float4 a0, a1, x0, x1;
+    float4 a0, a1, x[NJ];
   };
   // (Loads are unconditional, from clamped addresses, and masked afterwards: a load under a lane
   // condition compiles to a branch whose join waits for every outstanding load, which serialises
@@ -143,12 +147,13 @@ static __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvP p) {
     if (!in_k) tap = p.taps - 1, cc = chunks_per_tap - 1;
     f.a0 = W0[(size_t)cl * 64];
     f.a1 = W1[(size_t)cl * 64];
-    const int fs0 = ff[0] + tap - p.pad_left, fs1 = ff[1] + tap - p.pad_left;
-    const int fc0 = min(max(fs0, 0), p.F - 1), fc1 = min(max(fs1, 0), p.F - 1);
-    const float4 x0 = *reinterpret_cast<const float4*>(xbase[0] + (size_t)fc0 * p.x_pitch + cc * 8);
-    const float4 x1 = *reinterpret_cast<const float4*>(xbase[1] + (size_t)fc1 * p.x_pitch + cc * 8);
-    f.x0 = (in_k && fs0 >= 0 && fs0 < nf[0]) ? x0 : zero4;
-    f.x1 = (in_k && fs1 >= 0 && fs1 < nf[1]) ? x1 : zero4;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int fs = ff[j] + tap - p.pad_left;
+      const int fc = min(max(fs, 0), p.F - 1);
+      const float4 x = *reinterpret_cast<const float4*>(xbase[j] + (size_t)fc * p.x_pitch + cc * 8);
+      f.x[j] = (in_k && fs >= 0 && fs < nf[j]) ? x : zero4;
+    }
     return f;
   };
 #define TTSX_MFMA4(A, X, ACC)                                         \
@@ -157,10 +162,14 @@ static __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvP p) {
   ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(A.z, X.z, ACC, 0, 0, 0); \
   ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(A.w, X.w, ACC, 0, 0, 0);
   auto mma = [&](const Frag& f) {
-    TTSX_MFMA4(f.a0, f.x0, acc[0][0]);
-    TTSX_MFMA4(f.a0, f.x1, acc[0][1]);
-    TTSX_MFMA4(f.a1, f.x0, acc[1][0]);
-    TTSX_MFMA4(f.a1, f.x1, acc[1][1]);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      TTSX_MFMA4(f.a0, f.x[j], acc[0][j]);
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      TTSX_MFMA4(f.a1, f.x[j], acc[1][j]);
+    }
   };
   // software pipeline over the K chunks (tap-major): the operands of chunk c+1 are requested before
   // the 16 MFMAs of chunk c issue
@@ -185,7 +194,7 @@ static __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvP p) {
   for (int i = 0; i < 2; ++i) {
     if (!has_cb[i]) continue;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) store_tile(p, cb0 + i, acc[i][j], bb[j], ff[j], half);
+    for (int j = 0; j < NJ; ++j) store_tile(p, cb0 + i, acc[i][j], bb[j], ff[j], half);
   }
 }
 
@@ -279,8 +288,12 @@ static inline int layer_run(const Layer& L, const float* x, int x_pitch, float* 
   if ((long)grid.x * grid.y < 128) {
     dim3 sgrid((unsigned)((ncols + 31) / 32), ceil_div(L.cout, 32));
     conv_mfma_small_kernel<<<sgrid, 256, 0, st>>>(c);
+  } else if ((long)grid.x * grid.y <= 384) {
+    // fewer than three 128-frame tiles for two CUs: 64-frame tiles, two or three workgroups per CU
+    grid.x = (unsigned)((ncols + 63) / 64);
+    conv_mfma_kernel<1><<<grid, 256, 0, st>>>(c);
   } else {
-    conv_mfma_kernel<<<grid, 256, 0, st>>>(c);
+    conv_mfma_kernel<2><<<grid, 256, 0, st>>>(c);
   }
   TTSX_LAUNCH_CHECK();
   return TTSX_OK;
