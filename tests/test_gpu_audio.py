@@ -328,3 +328,20 @@ def test_griffin_lim_against_the_references_own_loop(name, v1):
         assert wav.dtype == np.float64 and wav.shape == g["wav%d" % F].shape
         snr = _snr_db(g["wav%d" % F], wav)
         assert snr >= 40.0, "%s F=%d end-to-end SNR %.1f dB" % (name, F, snr)
+
+
+@pytest.mark.parametrize("B,F,iters", [(1, 402, 60), (1, 6, 5), (3, 61, 8), (48, 300, 4)])
+def test_reflect_pad_written_by_the_launches_equals_the_pad_kernel(B, F, iters):
+    """Tacotron (v1) geometry ('reflect' centre padding).  With utterances of full length the Griffin-Lim launches
+    write the pad images themselves; with a length array (here: every length = F) a separate kernel fills the pad
+    between the launches.  Same samples either way, from one workgroup per round (B = 1) to runs of several rounds
+    with halo rounds (48 x 300); F = 6 is the shortest signal with one image per pad position + margin."""
+    _, ap = _aps(True, iters=iters)
+    g = torch.Generator(device="cpu").manual_seed(5 + F)
+    mag = (torch.rand(B, F, 1025, generator=g) * 2).cuda()
+    ph = torch.rand(B, F, 1025, generator=g).cuda()
+    own = ap.griffin_lim_batch(mag, ph)
+    by_kernel = ap.griffin_lim_batch(mag, ph, n_frames=torch.full((B,), F, dtype=torch.int32))
+    assert own.shape == by_kernel.shape
+    assert torch.isfinite(own).all()
+    assert torch.equal(own, by_kernel)

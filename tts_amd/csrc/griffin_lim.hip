@@ -729,9 +729,14 @@ struct FusedP {
   // block 2 three), and when its run is done it takes the left neighbour's carry and adds carry and terms in the
   // usual order - the same bits as with a halo round, one round of frames less per run.
   float* stash;
+  // 'reflect' centre padding written by the launch itself: the thread that emits sample m of the signal also
+  // writes its images in the head pad (n_fft/2 - m, 1 <= m <= n_fft/2) and in the tail pad (n_fft/2 + 2 L - 2 - m,
+  // L - 1 - n_fft/2 <= m <= L - 2); positions outside the signal are not written by their slot's owner.  Only for
+  // utterances of full length with L >= n_fft/2 + 2 (one image per pad position): the REFL forms of the kernel.
+  // Otherwise the pad is constant, or reflect_pad_kernel fills it between the launches.
 };
 
-template <int KIND, int PADDED, bool PRUNE = false>
+template <int KIND, int PADDED, bool PRUNE = false, bool REFL = false>
 __global__ __launch_bounds__(64 * FR_PER_WG, 3) void gl_fused_kernel(FusedP P) {
   __shared__ float2 s_tw[TW_ALL];
   __shared__ float2 s_tw2[516];
@@ -778,8 +783,8 @@ __global__ __launch_bounds__(64 * FR_PER_WG, 3) void gl_fused_kernel(FusedP P) {
   // beyond 256 are dealt one per thread (block tid / (hop - 256), offset 256 + tid % (hop - 256)).
   constexpr int NTHR = 64 * FR_PER_WG;
   const int n_left = q.hop - NTHR;  // offsets of a hop block beyond the first 256
-  const bool fast_geom = !xmode && q.win == FR_PER_WG * q.hop && P.carry_len == (FR_PER_WG - 1) * q.hop && n_left >= 0 &&
-                         (2 * FR_PER_WG - 1) * n_left <= NTHR;
+  const bool fast_geom = !xmode && !REFL && q.win == FR_PER_WG * q.hop && P.carry_len == (FR_PER_WG - 1) * q.hop &&
+                         n_left >= 0 && (2 * FR_PER_WG - 1) * n_left <= NTHR;
   float wss_left = 0.f;
   if (fast_geom && n_left > 0) {
     const int left_rho = NTHR + tid % n_left;
@@ -876,7 +881,17 @@ __global__ __launch_bounds__(64 * FR_PER_WG, 3) void gl_fused_kernel(FusedP P) {
             y = wss > 1.17549435e-38f ? acc / wss : acc;
           }
           if (PADDED) {
-            if (g < q.LP) P.out[(size_t)b * q.LP + g] = y;
+            if constexpr (REFL) {
+              if (m >= 0 && m < L) {
+                float* yb = P.out + (size_t)b * q.LP;
+                yb[g] = y;
+                if (m >= 1 && m <= NFFT / 2) yb[NFFT / 2 - m] = y;
+                const int k = L - 2 - m;
+                if (k >= 0 && k < NFFT / 2) yb[NFFT / 2 + L + k] = y;
+              }
+            } else if (g < q.LP) {
+              P.out[(size_t)b * q.LP + g] = y;
+            }
           } else {
             if (m >= 0 && m < Lmax) P.out[(size_t)b * Lmax + m] = y;
           }
@@ -1035,10 +1050,12 @@ __global__ __launch_bounds__(64 * FR_PER_WG, 3) void gl_fused_kernel(FusedP P) {
   }
   if (PADDED) {
     // the first lpad samples and the tail beyond the last round belong to nobody's slot
-    if (blockIdx.x == 0)
+    // (with the reflect images written above: only what lies beyond the tail pad)
+    if (blockIdx.x == 0 && !REFL)
       for (int g = tid; g < q.lpad; g += 64 * FR_PER_WG) P.out[(size_t)b * q.LP + g] = 0.f;
     if (j_end == P.n_rounds)
-      for (int g = q.lpad + P.n_rounds * FR_PER_WG * q.hop + tid; g < q.LP; g += 64 * FR_PER_WG)
+      for (int g = (REFL ? max(q.lpad + P.n_rounds * FR_PER_WG * q.hop, NFFT + L) : q.lpad + P.n_rounds * FR_PER_WG * q.hop) + tid;
+           g < q.LP; g += 64 * FR_PER_WG)
         P.out[(size_t)b * q.LP + g] = 0.f;
   }
 }
@@ -1379,16 +1396,19 @@ int enqueue_griffin_lim(const float2* tw, const float* winpad, float* const ybuf
   const dim3 grid(ceil_div(P.n_rounds, P.C), B), refl_grid(NFFT / 256, B);
   const size_t smem = 2 * (size_t)std::max(P.carry_len, 1) * sizeof(float);
   const bool reflect = sp->pad_mode == TTSX_PAD_REFLECT;
+  // (utterances of full length that are long enough for one image per pad position: the launches write the pad)
+  const bool own_pad = reflect && !n_frames && !defer && Lmax >= (size_t)NFFT / 2 + 2;
   const bool direct = preemph == 0.f;  // without de-emphasis the last launch writes the trimmed signal itself
   const bool prune = gl_prunable(q);
   int cur = 0;
   P.out = (direct && iters == 0) ? wav : ybuf[cur];
   if (exchange) P.xtag = ++*xtag;
   if (direct && iters == 0) gl_fused_kernel<K_GL_INIT, 0><<<grid, 64 * FR_PER_WG, smem, st>>>(P);
+  else if (own_pad) gl_fused_kernel<K_GL_INIT, 1, false, true><<<grid, 64 * FR_PER_WG, smem, st>>>(P);
   else gl_fused_kernel<K_GL_INIT, 1><<<grid, 64 * FR_PER_WG, smem, st>>>(P);
   TTSX_LAUNCH_CHECK();
   for (int it = 0; it < iters; ++it) {
-    if (reflect) reflect_pad_kernel<<<refl_grid, 256, 0, st>>>(ybuf[cur], n_frames, B, F, q);
+    if (reflect && !own_pad) reflect_pad_kernel<<<refl_grid, 256, 0, st>>>(ybuf[cur], n_frames, B, F, q);
     P.f.ypad = ybuf[cur];
     if (defer) P.xbuf = xbuf, P.stash = reinterpret_cast<float*>(xbuf + pl.xbuf_words);
     if (exchange || defer) P.xtag = ++*xtag;
@@ -1399,7 +1419,9 @@ int enqueue_griffin_lim(const float2* tw, const float* winpad, float* const ybuf
       else gl_fused_kernel<K_GL_ITER, 0><<<grid, 64 * FR_PER_WG, smem, st>>>(P);
     } else {
       P.out = ybuf[cur ^ 1];
-      if (prune) gl_fused_kernel<K_GL_ITER, 1, true><<<grid, 64 * FR_PER_WG, smem, st>>>(P);
+      if (own_pad && prune) gl_fused_kernel<K_GL_ITER, 1, true, true><<<grid, 64 * FR_PER_WG, smem, st>>>(P);
+      else if (own_pad) gl_fused_kernel<K_GL_ITER, 1, false, true><<<grid, 64 * FR_PER_WG, smem, st>>>(P);
+      else if (prune) gl_fused_kernel<K_GL_ITER, 1, true><<<grid, 64 * FR_PER_WG, smem, st>>>(P);
       else gl_fused_kernel<K_GL_ITER, 1><<<grid, 64 * FR_PER_WG, smem, st>>>(P);
     }
     TTSX_LAUNCH_CHECK();
