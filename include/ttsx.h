@@ -168,10 +168,14 @@ int ttsx_t2_decoder_set_plan(ttsx_t2_decoder* dec, int fused_attention, int spli
  * (rounding differs at 1e-6: six partial sums instead of two). */
 int ttsx_t2_decoder_set_pieces(ttsx_t2_decoder* dec, int staged);
 
-/* Batches on the MFMA engine (B > 2): prenet layer 2 of a step inside the projection launch of the step before it
- * (its workgroups wait for flags that the projection's row blocks raise: one launch boundary less per step).
- * No reference counterpart.  -1 where it measured faster (padded batch 64 with the early / late LSTM split), 0 never,
- * 1 on every batch above 2; the results are bit-equal either way. */
+/* Batches on the MFMA engine (B > 2): launches of a step folded into the launch that produces their input, their
+ * workgroups waiting for step tags that the producers raise (one launch boundary less per step each).  No
+ * reference counterpart.  1: prenet layer 2 of a step inside the projection launch of the step before it, on every
+ * batch above 2; 2: also the late columns of the decoder LSTM inside the attention launch, where that launch runs
+ * staged pieces (ttsx_t2_decoder_set_pieces); 0: neither; -1 (default): both where they measured faster (padded
+ * batch 64 with the early / late LSTM split).  The results are bit-equal in every setting.  A waiting workgroup
+ * that sees no tag within its bound makes the run start over without these launches (default setting) or
+ * return TTSX_ERR_STATE (settings 1, 2). */
 int ttsx_t2_decoder_set_fusion(ttsx_t2_decoder* dec, int prenet_in_projection);
 
 /* Whether a run of one or two utterances may use the persistent team kernel (no reference counterpart): texts of up to

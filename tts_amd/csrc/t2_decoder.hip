@@ -255,6 +255,11 @@ struct GemmP {
   // PROJ with prenet layer 2 of the next step in the same launch (Prenet2AfterProjOp): x1 leaves through
   // cache-bypassing stores and the row block then raises x1_flags[column tile * 16 + block] to the step's tag
   unsigned* x1_flags;
+  // The late decoder-LSTM columns inside the attention launch (GemmOp<..., LATE>): step tags raised by the producers
+  // of what they read - [2 b + w]: waves w = 0, 1 of utterance b's attention workgroup have stored their halves of
+  // the context; [2 Bpad + (part * nrb / 8 + row group) * 8 + w]: wave w of a staged piece has stored its partial
+  // sums.  Both kinds of data leave through coh_store16 and are read through coh_load16.  Null: off.
+  unsigned* late_flags;
   // GRU (Tacotron v1; rows of a hidden unit = r, z, n_input, n_hidden over K = [x; h]): h ping-pong in
   // `out` like the LSTM; with `resid` the launch also writes sum_out = h_new + resid (residual GRU stack)
   const float* resid;
@@ -275,6 +280,21 @@ struct GemmP {
   int step_in_chunk;
 };
 
+// 16-byte accesses past the (per-XCD, not mutually coherent) L2, for data that workgroups of ONE launch hand to
+// each other: buffer instructions with the system-coherent cache policy.  Unlike volatile accesses (a wait after
+// each) or inline assembly (loads the compiler does not count) they are scheduled and waited for like any other
+// load.  `base` is wave-uniform; the offset is in bytes (buffers here are far below 2 GB).
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+constexpr int COHERENT_POLICY = 17;  // sc0 | sc1
+__device__ __forceinline__ f32x4 coh_load16(const void* base, unsigned byte_off) {
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, COHERENT_POLICY));
+}
+__device__ __forceinline__ void coh_store16(void* base, unsigned byte_off, f32x4 v) {
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7fffffff, 0x00020000);
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), r, (int)byte_off, 0, COHERENT_POLICY);
+}
+
 // K parts of the decoder LSTM's early columns when its pieces stage their activations in LDS (StagedPieceOp)
 constexpr int STAGED_PARTS = 6;
 
@@ -283,7 +303,7 @@ struct Pre {
   float4 bias, gates;
   float c;
 };
-template <int MODE>
+template <int MODE, bool COH = false>
 __device__ __forceinline__ Pre prefetch_quad(const GemmP& p, int quad, int b) {
   Pre r;
   r.bias = make_float4(0.f, 0.f, 0.f, 0.f), r.gates = r.bias, r.c = 0.f;
@@ -291,7 +311,17 @@ __device__ __forceinline__ Pre prefetch_quad(const GemmP& p, int quad, int b) {
   if (MODE == MODE_LSTM) {
     r.c = p.c[qidx(quad, b, p.Bpad)];
     const int gp = p.gates_pitch ? p.gates_pitch : p.Bpad;
-    if (p.gates) {
+    if (COH) {
+      // the partial sums of staged pieces of this same launch, added in part order
+      const unsigned off = (unsigned)(((size_t)quad * gp + p.gates_col0 + b) * sizeof(float4));
+      f32x4 gk[STAGED_PARTS];
+#pragma unroll
+      for (int k = 0; k < STAGED_PARTS; ++k) gk[k] = coh_load16(p.gates, off + (unsigned)(k * p.gates_part_stride * sizeof(float4)));
+      f32x4 sum = gk[0];
+#pragma unroll
+      for (int k = 1; k < STAGED_PARTS; ++k) sum += gk[k];
+      r.gates = make_float4(sum[0], sum[1], sum[2], sum[3]);
+    } else if (p.gates) {
       const float4* G = reinterpret_cast<const float4*>(p.gates) + (size_t)quad * gp + p.gates_col0 + b;
       r.gates = G[0];
       if (p.kparts == STAGED_PARTS) {
@@ -431,11 +461,18 @@ __device__ __forceinline__ const float* seg_ptr(const Seg& sg, int parity) {
 // DYN: the combine buffer lives in the launch's dynamic LDS instead of a static array (for pieces that share a
 // launch with the fused attention kernel: its ~55 KB of dynamic LDS are unused by the piece workgroups, and a
 // second 32 KB static array would push the launch past two workgroups per CU).
-template <int R, int NT, int KGW, int MODE, bool DYN = false>
+// LATE (the decoder LSTM's columns over the context, 32 x 32 tiles, inside the launch that forms the context): the
+// workgroup requests its weights, then every wave waits for the step tags of the producers of what it reads - the
+// attention workgroups of its 32 utterances and the staged pieces of its rows (p.late_flags) - and reads the context
+// tiles and the six partial sums past the L2.  Its block indices come after the producers', so they are running
+// or done when it starts; the wait is bounded all the same (RunCtx::sync_failed).
+template <int R, int NT, int KGW, int MODE, bool DYN = false, bool LATE = false>
 struct GemmOp {
   typedef GemmP P;
   static __device__ __forceinline__ void run(const GemmP& p, int wg_in) {
     int wg = wg_in;
+    static_assert(!LATE || (R == 2 && NT == 2 && MODE == MODE_LSTM && KGW <= 4), "the late op: 32 x 32 tiles, every k-group up front");
+    if (LATE && step_done(p.ctx, p.step_in_chunk)) return;  // (the producers raise no flags for such a step)
     if (KGW == 20) FA_MARK(8);
     // (the projection is on the step's serial path and shares its CUs with piece workgroups: its waves go first)
     if (MODE == MODE_PROJ) __builtin_amdgcn_s_setprio(3);
@@ -480,13 +517,53 @@ struct GemmOp {
       return g < e0 ? X0 + (size_t)g * xs : (g < e1 ? X1 + (size_t)(g - e0) * xs : X2 + (size_t)(g - e1) * xs);
     };
     float4 wv[D][R], xv[D][NT];
+    // (LATE) the step tags this wave waits for.  lane l: wave l & 1 of the attention workgroup of utterance
+    // b0 + l / 2 (padding columns have none); lanes 0-11 also: the staged piece of part l / 2 that holds row block
+    // rb + (l & 1).  Most workgroups start when their producers are through: one look at the tags BEFORE anything
+    // else is requested (vector loads return in order - behind the weights the answer would come 2 us later), and
+    // if they are all up, weights, context tiles and partial sums leave in one burst.
+    unsigned late_tag = 0;
+    const unsigned *late_fa = nullptr, *late_fp = nullptr;
+    bool late_ready = false;
+    auto late_look = [&]() {
+      const unsigned a = b0 + (lane >> 1) < p.ctx->B ? __hip_atomic_load(late_fa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : late_tag;
+      const unsigned b = lane < 2 * STAGED_PARTS ? __hip_atomic_load(late_fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : late_tag;
+      return __all(a == late_tag && b == late_tag) != 0;
+    };
+    if constexpr (LATE) {
+      late_tag = (unsigned)(p.ctx->base + p.step_in_chunk + 1);
+      late_fa = p.late_flags + 2 * min(b0 + (lane >> 1), p.Bpad - 1) + (lane & 1);
+      late_fp = p.late_flags + 2 * p.Bpad +
+                ((min(lane >> 1, STAGED_PARTS - 1) * (p.nrb / GEMM_WAVES) + rb / GEMM_WAVES) * GEMM_WAVES + (rb % GEMM_WAVES) + (lane & 1));
+      late_ready = late_look();
+    }
 #pragma unroll
     for (int i = 0; i < D; ++i) {
 #pragma unroll
       for (int r = 0; r < R; ++r) wv[i][r] = W[(size_t)i * GEMM_WAVES * 64 + r * wrs];
-      const float4* xp = xptr(wave + i * GEMM_WAVES);
+      if constexpr (!LATE) {
+        const float4* xp = xptr(wave + i * GEMM_WAVES);
 #pragma unroll
-      for (int n = 0; n < NT; ++n) xv[i][n] = xp[n * 16];
+        for (int n = 0; n < NT; ++n) xv[i][n] = xp[n * 16];
+      }
+    }
+    if constexpr (LATE) {
+      for (long spin = 0; !late_ready && spin < 4000000; ++spin) {
+        __builtin_amdgcn_s_sleep(1);
+        late_ready = late_look();
+      }
+      if (!late_ready) {
+        if (threadIdx.x == 0) p.ctx->sync_failed = 1;
+        return;  // (no barrier has been passed: the waves of the workgroup leave one by one)
+      }
+      const float* xb = seg_ptr(p.seg[0], p.parity);
+#pragma unroll
+      for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const f32x4 v = coh_load16(xb, (unsigned)((xoff + (size_t)(wave + i * GEMM_WAVES + kbase) * xs + n * 16) * sizeof(float4)));
+          xv[i][n] = make_float4(v[0], v[1], v[2], v[3]);
+        }
     }
     // query-projection share: thread (d = tid & 127, cg = tid >> 7) covers columns cg*4*NT .. +4*NT-1
     constexpr int QU = 4 * R, QC = 4 * NT;
@@ -503,7 +580,7 @@ struct GemmOp {
     for (int k = 0; k < TPW; ++k) {
       const int t = wave + k * GEMM_WAVES;
       if (t < TILES)
-        pre[k] = prefetch_quad<MODE>(p, (rb + t / NT) * 4 + (lane >> 4), b0 + (t % NT) * 16 + (lane & 15));
+        pre[k] = prefetch_quad<MODE, LATE>(p, (rb + t / NT) * 4 + (lane >> 4), b0 + (t % NT) * 16 + (lane & 15));
     }
 
     f32x4 acc[R][NT];
@@ -525,7 +602,7 @@ struct GemmOp {
       TTSX_SLICE(z)
       TTSX_SLICE(w)
 #undef TTSX_SLICE
-      if (i + D < KGW) {
+      if (!LATE && i + D < KGW) {
 #pragma unroll
         for (int r = 0; r < R; ++r) wv[sl][r] = W[(size_t)(i + D) * GEMM_WAVES * 64 + r * wrs];
         const float4* xp = xptr(wave + (i + D) * GEMM_WAVES);
@@ -665,8 +742,18 @@ struct StagedPieceOp {
 #undef TTSX_KGROUP
 #undef TTSX_SLICE
     if (done) return;
-    float4* O = reinterpret_cast<float4*>(p.gates) + (size_t)part * p.gates_part_stride +
-                (size_t)(rb * 4 + (lane >> 4)) * p.Bpad + (lane & 15);
+    const size_t o0 = (size_t)part * p.gates_part_stride + (size_t)(rb * 4 + (lane >> 4)) * p.Bpad + (lane & 15);
+    if (p.late_flags) {
+      // read by the late decoder-LSTM workgroups of this launch: past the L2, then this wave's step tag
+#pragma unroll
+      for (int n = 0; n < 4; ++n) coh_store16(p.gates, (unsigned)((o0 + n * 16) * sizeof(float4)), acc[n]);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0)
+        __hip_atomic_store(p.late_flags + 2 * p.Bpad + ((part * nrg + wg % nrg) * GEMM_WAVES + wave),
+                           (unsigned)(p.ctx->base + p.step_in_chunk + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+    float4* O = reinterpret_cast<float4*>(p.gates) + o0;
 #pragma unroll
     for (int n = 0; n < 4; ++n) O[n * 16] = make_float4(acc[n][0], acc[n][1], acc[n][2], acc[n][3]);
   }
@@ -893,6 +980,7 @@ struct AttnP {
   float* a_cum;          // [B][T]
   float* energies;       // [B][T]
   float* ctx_out;        // quad [512]
+  unsigned* late_flags;  // (fused kernel) see GemmP::late_flags; null: off
   const float* enc;      // [B][T][512] encoder outputs (the decoder's own copy: a stable address)
   const int32_t* len;    // [B] valid encoder positions per utterance
   RunCtx* ctx;
@@ -1632,7 +1720,16 @@ struct FusedAttnOp {
         const float4 w = s_acc[g * LPR + tid];
         tot.x += w.x, tot.y += w.y, tot.z += w.z, tot.w += w.w;
       }
-      reinterpret_cast<float4*>(p.ctx_out)[(size_t)tid * p.Bpad + b] = tot;
+      if (p.late_flags) {
+        // read by the late decoder-LSTM workgroups of this launch: past the L2, then this wave's step tag
+        coh_store16(p.ctx_out, (unsigned)(((size_t)tid * p.Bpad + b) * sizeof(float4)), (f32x4){tot.x, tot.y, tot.z, tot.w});
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0)
+          __hip_atomic_store(p.late_flags + 2 * b + wave, (unsigned)(cx->base + p.step_in_chunk + 1), __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        reinterpret_cast<float4*>(p.ctx_out)[(size_t)tid * p.Bpad + b] = tot;
+      }
     }
     FA_MARK(6);
   }
@@ -1821,7 +1918,9 @@ struct ttsx_t2_decoder {
   int plan_fused, plan_split, plan_share_q;  // ttsx_t2_decoder_set_plan: -1 by shape (default), 0 off, 1 on
   bool share_q;  // three-launch attention without the query launch: the energies op adds up the query shares
   unsigned* x1_flags;  // [Bpad / 16][16] step tags of the prenet layer-1 row blocks (Prenet2AfterProjOp)
-  int plan_fuse_p2;    // ttsx_t2_decoder_set_fusion: prenet layer 2 of the next step inside the projection launch
+  unsigned* late_flags;  // [2 Bpad + STAGED_PARTS * 256] step tags for the late decoder-LSTM columns inside the attention launch
+  int plan_fuse_p2;    // ttsx_t2_decoder_set_fusion: prenet layer 2 of the next step inside the projection launch (1), and
+                       // the late decoder-LSTM columns inside the attention launch as well (2); -1: where measured faster
   bool fuse_gave_up;   // a prenet workgroup of that launch once waited too long: the default plan no longer fuses
   // one utterance, short text, plain attention: the whole run as one persistent launch with the weights on chip
   t2_team* team;
@@ -1907,6 +2006,8 @@ void free_workspace(ttsx_t2_decoder* d) {
   d->win_idx = nullptr;
   if (d->x1_flags) (void)hipFree(d->x1_flags);
   d->x1_flags = nullptr;
+  if (d->late_flags) (void)hipFree(d->late_flags);
+  d->late_flags = nullptr;
   d->cap_B = 0;
 }
 
@@ -1940,6 +2041,7 @@ int ensure_workspace(ttsx_t2_decoder* d, int B, int T) {
     rc |= dev_alloc(&d->u_fa, cb);
     rc |= dev_alloc(&d->win_idx, cb);
     rc |= dev_alloc(&d->x1_flags, (size_t)ceil_div((int)cb, 16) * (PRENET_DIM / 16));
+    rc |= dev_alloc(&d->late_flags, 2 * cb + (size_t)STAGED_PARTS * (DEC_DIM / 4));
     rc |= dev_alloc(&d->mu, cb * GRAVES_MAX_K);
     rc |= dev_alloc(&d->n1, QUERY_DIM * cb);
     rc |= dev_alloc(&d->gbk, (size_t)round_up(3 * GRAVES_MAX_K, 16) * cb);
@@ -2266,7 +2368,11 @@ int enqueue_step(ttsx_t2_decoder* d, int i, bool first, bool more, hipStream_t s
   // (measured per step, own launch / fused, T=128 unless noted: B=32 38.7 / 39.9 us, B=48 48.1 / 46.9, B=64 48.2 /
   // 46.6, B=64 T=256 52.2 / 50.9, B=64 T=64 (no split) 49.1 / 51.4, B=128 (no split) 73.3 / 76.4: it pays where the
   // early/late split is on at padded batch 64, and costs where the fused launch has no piece work to hide behind)
-  const bool fuse_p2 = mfma && (d->plan_fuse_p2 == 1 || (d->plan_fuse_p2 == -1 && !d->fuse_gave_up && split && Bpad == 64));
+  const bool fuse_p2 = mfma && (d->plan_fuse_p2 >= 1 || (d->plan_fuse_p2 == -1 && !d->fuse_gave_up && split && Bpad == 64));
+  // the late decoder-LSTM columns inside the attention launch: where that launch gives every workgroup a CU of
+  // its own (staged pieces) and the plain fused attention runs
+  const bool late_in_attn = mfma && split && d->fused && d->staged && pd.g.kparts == STAGED_PARTS && T <= 128 && Bpad == 64 &&
+                            d->graves_K == 0 && (d->plan_fuse_p2 == 2 || (d->plan_fuse_p2 == -1 && !d->fuse_gave_up));
   // (pieces of the attention partial: thirds of the rows behind decoder LSTM / projection / prenet at batch 1-2;
   // on the MFMA engine the two halves of K behind projection / prenet)
   pc = mfma ? k_piece(pa, 1) : pa.piece(2);
@@ -2318,7 +2424,31 @@ int enqueue_step(ttsx_t2_decoder* d, int i, bool first, bool more, hipStream_t s
     pc = Piece{pd.g, split};
     pc.g.rb0 = 0, pc.g.nrb = pd.total_rb, pc.nk = pd.g.kparts;
     const size_t smem = sizeof(float) * FA_LDS_FLOATS;
-    if (T <= 128 && split && Bpad >= 64) rc = launch_with_piece<FusedAttnOp<1, ENC_DIM, 16>, PK2>(d, ap, B, smem, &pc, st);
+    if (late_in_attn) {
+      // + the late decoder-LSTM columns behind the step tags of this launch's own attention workgroups and pieces:
+      // one launch boundary less
+      typedef FusedAttnOp<1, ENC_DIM, 16> AttnOp;
+      typedef StagedPieceOp<PK2 * GEMM_WAVES, STAGED_PARTS> PieceOp;
+      typedef GemmOp<2, 2, 4, MODE_LSTM, false, true> LateOp;
+      ap.late_flags = d->late_flags, pc.g.late_flags = d->late_flags;
+      GemmP gl = g;
+      gl.Wp = d->w_lstm2, gl.bias = d->b_lstm2, gl.kg0 = 0, gl.kg_stride = KG2;
+      gl.seg[0] = Seg{{d->ctx, nullptr}, 0, ENC_DIM / 16};
+      gl.out[0] = d->h_d[0], gl.out[1] = d->h_d[1], gl.c = d->c_d, gl.relu = 0;
+      gl.nseg = 1, gl.KG = ENC_DIM / 16, gl.gates = d->g_d;
+      gl.kparts = pd.g.kparts, gl.gates_part_stride = pd.g.gates_part_stride;
+      gl.rb0 = 0, gl.nrb = DEC_DIM / 4, gl.late_flags = d->late_flags;
+      const int nb = pc.g.nrb / GEMM_WAVES * pc.nk, nl = (DEC_DIM / 4) / 2 * (Bpad / 32);
+      const size_t lds = std::max(std::max(smem, (size_t)PieceOp::LDS_BYTES), STAGED_LDS_MIN);
+      static bool raised = false;
+      if (!raised) {
+        TTSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(triple_kernel_b_first<AttnOp, LateOp, PieceOp>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        raised = true;
+      }
+      triple_kernel_b_first<AttnOp, LateOp, PieceOp><<<B + nb + nl, GEMM_THREADS, lds, st>>>(ap, gl, pc.g, B, nb);
+      TTSX_LAUNCH_CHECK();
+    } else if (T <= 128 && split && Bpad >= 64) rc = launch_with_piece<FusedAttnOp<1, ENC_DIM, 16>, PK2>(d, ap, B, smem, &pc, st);
     else if (T <= 128) rc = launch_with_piece<FusedAttnOp<1, ENC_DIM>, PK2>(d, ap, B, smem, &pc, st);
     else if (T <= 256) rc = launch_with_piece<FusedAttnOp<2, ENC_DIM>, PK2>(d, ap, B, smem, &pc, st);
     else rc = launch_with_piece<FusedAttnOp<4, ENC_DIM>, PK2>(d, ap, B, smem, &pc, st);
@@ -2372,7 +2502,9 @@ int enqueue_step(ttsx_t2_decoder* d, int i, bool first, bool more, hipStream_t s
   g.out[0] = d->h_d[0], g.out[1] = d->h_d[1], g.c = d->c_d;
   pc = pa_next.piece(0);
   pc.on = split && more && !mfma;
-  if (split) {
+  if (late_in_attn) {
+    rc = TTSX_OK;  // (ran inside the attention launch)
+  } else if (split) {
     g.nseg = 1, g.KG = ENC_DIM / 16, g.gates = d->g_d;
     g.kparts = pd.g.kparts, g.gates_part_stride = pd.g.gates_part_stride;
     rc = launch_gemm<MODE_LSTM, 4, PK1>(d, g, DEC_DIM / 4, true, &pc, st);
@@ -2732,6 +2864,7 @@ extern "C" int ttsx_t2_decoder_begin(ttsx_t2_decoder* d, const float* enc, const
   TTSX_HIP(hipMemsetAsync(d->n1, 0, sizeof(float) * QUERY_DIM * cb, st));
   TTSX_HIP(hipMemsetAsync(d->gbk, 0, sizeof(float) * (size_t)round_up(3 * GRAVES_MAX_K, 16) * cb, st));
   TTSX_HIP(hipMemsetAsync(d->x1_flags, 0, sizeof(unsigned) * ceil_div((int)cb, 16) * (PRENET_DIM / 16), st));
+  TTSX_HIP(hipMemsetAsync(d->late_flags, 0, sizeof(unsigned) * (2 * cb + (size_t)STAGED_PARTS * (DEC_DIM / 4)), st));
   TTSX_HIP(hipMemsetAsync(d->a_prev, 0, sizeof(float) * (size_t)B * T, st));
   TTSX_HIP(hipMemsetAsync(d->a_cum, 0, sizeof(float) * (size_t)B * T, st));
   if (d->mem0_set) {
@@ -2971,8 +3104,9 @@ extern "C" int ttsx_t2_decoder_set_plan(ttsx_t2_decoder* d, int fused_attention,
 
 extern "C" int ttsx_t2_decoder_set_fusion(ttsx_t2_decoder* d, int prenet_in_projection) {
   TTSX_ARG(d, "ttsx_t2_decoder_set_fusion: null handle");
-  TTSX_ARG(prenet_in_projection >= -1 && prenet_in_projection <= 1,
-           "ttsx_t2_decoder_set_fusion: %d is not -1 (default), 0 (off) or 1 (on)", prenet_in_projection);
+  TTSX_ARG(prenet_in_projection >= -1 && prenet_in_projection <= 2,
+           "ttsx_t2_decoder_set_fusion: %d is not -1 (default), 0 (off), 1 (prenet layer 2) or 2 (+ late decoder LSTM)",
+           prenet_in_projection);
   d->plan_fuse_p2 = prenet_in_projection;
   return TTSX_OK;
 }

@@ -329,7 +329,8 @@ class Tacotron2:
                                                         int(share_query)), "ttsx_t2_decoder_set_plan")
 
     def set_fusion(self, prenet_in_projection=-1):
-        """Batched decode: prenet layer 2 inside the previous step's projection launch (ttsx_t2_decoder_set_fusion)."""
+        """Batched decode: 1 = prenet layer 2 inside the previous step's projection launch, 2 = also the late decoder-LSTM
+        columns inside the attention launch, 0 = neither, -1 = by shape (ttsx_t2_decoder_set_fusion)."""
         _lib.check(_lib.load().ttsx_t2_decoder_set_fusion(self._dec_handle, int(prenet_in_projection)),
                    "ttsx_t2_decoder_set_fusion")
 
