@@ -92,11 +92,13 @@ static __device__ __forceinline__ void store_tile(const ConvP& p, int cb, const 
   }
 }
 
-// Block = 4 waves as 2 (Cout) x 2 (frames); each wave owns a 64 x (32 NJ) output tile held as
-// 2 x NJ accumulators of 32 x 32.  Block tile: 128 channels x 128 frames (NJ = 2), or x 64 frames (NJ = 1) for
-// problems whose 128-frame tiles would leave every SIMD with a single wave: one wave cannot cover the latency of
-// its own operand loads (55 % of the matrix rate measured on 256 tiles, K = 2560).
-template <int NJ>
+// Block = 4 waves as 2 (Cout) x 2 (frames); each wave owns a 64 x 32 output tile held as two accumulators of
+// 32 x 32.  Block tile: 128 channels x 64 frames.  (128-frame block tiles - 64 x 64 per wave, 216 registers, two
+// waves per SIMD - measured slower everywhere: on small problems they leave a SIMD with a single wave, which cannot
+// cover the latency of its own operand loads (encoder convs at 64 x 128: 286 against 200 us per layer), and on
+// large ones the last of 3.1 rounds of tiles runs on an eighth of the chip (postnet at 64 x 800: 4.8 against
+// 4.5 ms); here four waves fit a SIMD and the tail is a quarter as long.)
+constexpr int NJ = 1;
 static __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvP p) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int wm = wave >> 1, wn = wave & 1;
@@ -288,12 +290,9 @@ static inline int layer_run(const Layer& L, const float* x, int x_pitch, float* 
   if ((long)grid.x * grid.y < 128) {
     dim3 sgrid((unsigned)((ncols + 31) / 32), ceil_div(L.cout, 32));
     conv_mfma_small_kernel<<<sgrid, 256, 0, st>>>(c);
-  } else if ((long)grid.x * grid.y <= 384) {
-    // fewer than three 128-frame tiles for two CUs: 64-frame tiles, two or three workgroups per CU
-    grid.x = (unsigned)((ncols + 63) / 64);
-    conv_mfma_kernel<1><<<grid, 256, 0, st>>>(c);
   } else {
-    conv_mfma_kernel<2><<<grid, 256, 0, st>>>(c);
+    grid.x = (unsigned)((ncols + 63) / 64);
+    conv_mfma_kernel<<<grid, 256, 0, st>>>(c);
   }
   TTSX_LAUNCH_CHECK();
   return TTSX_OK;

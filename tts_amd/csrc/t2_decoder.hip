@@ -3074,14 +3074,14 @@ extern "C" int ttsx_t2_decoder_run(ttsx_t2_decoder* d, const float* enc, const i
   TTSX_HIP(hipStreamSynchronize(st));
   if (sync_failed) {
     // (workgroups of one launch that were not resident together.)  Under the default plan the handle stops fusing
-    // and the run starts over with prenet layer 2 as a launch of its own; state handed over by set_initial was
+    // and the run starts over with prenet layer 2 and the late decoder LSTM as launches of their own; state handed over by set_initial was
     // consumed by the failed attempt, so such a run reports the error instead.
     if (d->plan_fuse_p2 == -1 && !d->fuse_gave_up && !carried) {
       d->fuse_gave_up = true;
       return ttsx_t2_decoder_run(d, enc, enc_len, B, T, r, max_steps, stop_threshold, fixed_steps, mel, align, stop,
                                  n_steps, steps_run_host, stream);
     }
-    ttsx_set_error("ttsx_t2_decoder_run: a prenet workgroup waited too long for the projection rows of its own launch");
+    ttsx_set_error("ttsx_t2_decoder_run: a workgroup waited too long for the step tags of its own launch (ttsx_t2_decoder_set_fusion)");
     return TTSX_ERR_STATE;
   }
   int run = 0;
