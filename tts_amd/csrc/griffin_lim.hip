@@ -736,7 +736,10 @@ struct FusedP {
   // Otherwise the pad is constant, or reflect_pad_kernel fills it between the launches.
 };
 
-template <int KIND, int PADDED, bool PRUNE = false, bool REFL = false>
+// ONE: one round per workgroup with the carry from the left neighbour (FusedP::xbuf; batch 1 and other small
+// workloads).  Such a launch is as long as its chain of memory round trips, so the iteration form requests the
+// frame's samples before the tables, not after them.
+template <int KIND, int PADDED, bool PRUNE = false, bool REFL = false, bool ONE = false>
 __global__ __launch_bounds__(64 * FR_PER_WG, 3) void gl_fused_kernel(FusedP P) {
   __shared__ float2 s_tw[TW_ALL];
   __shared__ float2 s_tw2[516];
@@ -752,6 +755,10 @@ __global__ __launch_bounds__(64 * FR_PER_WG, 3) void gl_fused_kernel(FusedP P) {
   const int L = q.hop * (Fb - 1), Lmax = q.hop * (p.F - 1);
   const int shift = q.lpad - (q.lpad & ~1);
   const int K = (q.win + q.hop - 1) / q.hop;
+  [[maybe_unused]] FrameIn fin_early;
+  if constexpr (ONE && KIND == K_GL_ITER) {
+    if (FR_PER_WG * (int)blockIdx.x + wave < Fb) frame_prefetch<PRUNE>(p, b, FR_PER_WG * (int)blockIdx.x + wave, lane, fin_early);
+  }
   load_tables(s_tw, s_tw2, p.tw, tid);
   for (int t = tid; t < 2 * P.carry_len; t += 64 * FR_PER_WG) s_carry[t] = 0.f;
   const int j_first = blockIdx.x * P.C, j_end = min(j_first + P.C, P.n_rounds);
@@ -776,8 +783,8 @@ __global__ __launch_bounds__(64 * FR_PER_WG, 3) void gl_fused_kernel(FusedP P) {
   }
   const float inv_hop = 1.0f / (float)q.hop;
   int cur = 0;
-  const bool dmode = KIND == K_GL_ITER && P.stash != nullptr;
-  const bool xmode = P.xbuf != nullptr && !dmode;
+  const bool dmode = !ONE && KIND == K_GL_ITER && P.stash != nullptr;
+  constexpr bool xmode = ONE;
   // Interior rounds of the usual geometry (window = 4 hops, 256 <= hop <= 292) take combine_interior below: thread
   // tid owns offset rho = tid of each of the seven hop blocks of the round's span, and the 7 (hop - 256) offsets
   // beyond 256 are dealt one per thread (block tid / (hop - 256), offset 256 + tid % (hop - 256)).
@@ -809,9 +816,13 @@ __global__ __launch_bounds__(64 * FR_PER_WG, 3) void gl_fused_kernel(FusedP P) {
 #endif
     if (i < Fb) {
       if constexpr (KIND == K_GL_ITER) {
-        FrameIn fin;
-        frame_prefetch<PRUNE>(p, b, i, lane, fin);
-        frame_iter<PRUNE>(p, b, i, s_data[wave], s_tw, s_tw2, lane, fin, mark);
+        if constexpr (ONE) {
+          frame_iter<PRUNE>(p, b, i, s_data[wave], s_tw, s_tw2, lane, fin_early, mark);
+        } else {
+          FrameIn fin;
+          frame_prefetch<PRUNE>(p, b, i, lane, fin);
+          frame_iter<PRUNE>(p, b, i, s_data[wave], s_tw, s_tw2, lane, fin, mark);
+        }
       }
       else frame_body<KIND, true>(p, b, i, s_data[wave], s_tw, s_tw2, lane);
     }
@@ -1378,6 +1389,22 @@ bool gl_prunable(const FrameGeom& q) {
   return q.lpad >= 2 * 192 && q.lpad + q.win <= 2 * 832 && lpe + WP <= 2 * 832;
 }
 
+// One padded iteration launch in the form the plan asks for.
+void gl_iter_padded(bool one, bool refl, bool prune, dim3 grid, size_t smem, hipStream_t st, const FusedP& P) {
+  constexpr int NT = 64 * FR_PER_WG;
+  const int form = (one ? 4 : 0) | (refl ? 2 : 0) | (prune ? 1 : 0);
+  switch (form) {
+    case 0: gl_fused_kernel<K_GL_ITER, 1, false, false, false><<<grid, NT, smem, st>>>(P); break;
+    case 1: gl_fused_kernel<K_GL_ITER, 1, true, false, false><<<grid, NT, smem, st>>>(P); break;
+    case 2: gl_fused_kernel<K_GL_ITER, 1, false, true, false><<<grid, NT, smem, st>>>(P); break;
+    case 3: gl_fused_kernel<K_GL_ITER, 1, true, true, false><<<grid, NT, smem, st>>>(P); break;
+    case 4: gl_fused_kernel<K_GL_ITER, 1, false, false, true><<<grid, NT, smem, st>>>(P); break;
+    case 5: gl_fused_kernel<K_GL_ITER, 1, true, false, true><<<grid, NT, smem, st>>>(P); break;
+    case 6: gl_fused_kernel<K_GL_ITER, 1, false, true, true><<<grid, NT, smem, st>>>(P); break;
+    default: gl_fused_kernel<K_GL_ITER, 1, true, true, true><<<grid, NT, smem, st>>>(P); break;
+  }
+}
+
 // `xbuf` / `xtag`: carry words and launch counter of a handle (null: always halo rounds).
 int enqueue_griffin_lim(const float2* tw, const float* winpad, float* const ybuf[2], const float* mag,
                         const float* init_phase, const int32_t* n_frames, int B, int F, const ttsx_stft_params* sp,
@@ -1403,9 +1430,16 @@ int enqueue_griffin_lim(const float2* tw, const float* winpad, float* const ybuf
   int cur = 0;
   P.out = (direct && iters == 0) ? wav : ybuf[cur];
   if (exchange) P.xtag = ++*xtag;
-  if (direct && iters == 0) gl_fused_kernel<K_GL_INIT, 0><<<grid, 64 * FR_PER_WG, smem, st>>>(P);
-  else if (own_pad) gl_fused_kernel<K_GL_INIT, 1, false, true><<<grid, 64 * FR_PER_WG, smem, st>>>(P);
-  else gl_fused_kernel<K_GL_INIT, 1><<<grid, 64 * FR_PER_WG, smem, st>>>(P);
+  if (direct && iters == 0) {
+    if (exchange) gl_fused_kernel<K_GL_INIT, 0, false, false, true><<<grid, 64 * FR_PER_WG, smem, st>>>(P);
+    else gl_fused_kernel<K_GL_INIT, 0><<<grid, 64 * FR_PER_WG, smem, st>>>(P);
+  } else if (own_pad) {
+    if (exchange) gl_fused_kernel<K_GL_INIT, 1, false, true, true><<<grid, 64 * FR_PER_WG, smem, st>>>(P);
+    else gl_fused_kernel<K_GL_INIT, 1, false, true><<<grid, 64 * FR_PER_WG, smem, st>>>(P);
+  } else {
+    if (exchange) gl_fused_kernel<K_GL_INIT, 1, false, false, true><<<grid, 64 * FR_PER_WG, smem, st>>>(P);
+    else gl_fused_kernel<K_GL_INIT, 1><<<grid, 64 * FR_PER_WG, smem, st>>>(P);
+  }
   TTSX_LAUNCH_CHECK();
   for (int it = 0; it < iters; ++it) {
     if (reflect && !own_pad) reflect_pad_kernel<<<refl_grid, 256, 0, st>>>(ybuf[cur], n_frames, B, F, q);
@@ -1415,14 +1449,13 @@ int enqueue_griffin_lim(const float2* tw, const float* winpad, float* const ybuf
     const bool last = it + 1 == iters;
     if (last && direct) {
       P.out = wav;
-      if (prune) gl_fused_kernel<K_GL_ITER, 0, true><<<grid, 64 * FR_PER_WG, smem, st>>>(P);
+      if (exchange && prune) gl_fused_kernel<K_GL_ITER, 0, true, false, true><<<grid, 64 * FR_PER_WG, smem, st>>>(P);
+      else if (exchange) gl_fused_kernel<K_GL_ITER, 0, false, false, true><<<grid, 64 * FR_PER_WG, smem, st>>>(P);
+      else if (prune) gl_fused_kernel<K_GL_ITER, 0, true><<<grid, 64 * FR_PER_WG, smem, st>>>(P);
       else gl_fused_kernel<K_GL_ITER, 0><<<grid, 64 * FR_PER_WG, smem, st>>>(P);
     } else {
       P.out = ybuf[cur ^ 1];
-      if (own_pad && prune) gl_fused_kernel<K_GL_ITER, 1, true, true><<<grid, 64 * FR_PER_WG, smem, st>>>(P);
-      else if (own_pad) gl_fused_kernel<K_GL_ITER, 1, false, true><<<grid, 64 * FR_PER_WG, smem, st>>>(P);
-      else if (prune) gl_fused_kernel<K_GL_ITER, 1, true><<<grid, 64 * FR_PER_WG, smem, st>>>(P);
-      else gl_fused_kernel<K_GL_ITER, 1><<<grid, 64 * FR_PER_WG, smem, st>>>(P);
+      gl_iter_padded(exchange, own_pad, prune, grid, smem, st, P);
     }
     TTSX_LAUNCH_CHECK();
     cur ^= 1;
