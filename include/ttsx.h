@@ -395,7 +395,7 @@ int ttsx_t1_encoder_run(ttsx_t1* m, const float* emb, const int32_t* lengths, in
  * lengths [B] int32 or NULL as above: attention runs over the first lengths[b] positions and the
  * stop rule uses that length; align columns beyond it are zero.  Rows of mel / align / stop past
  * n_steps[b] are not written.  T <= 512.  Synchronises `stream`.
- * At batch 1-2 with T <= 128 the whole loop is one persistent launch of a 33-workgroup team per utterance that
+ * At batch 1-2 with T <= 128 the whole loop is one persistent launch of a 36-workgroup team per utterance that
  * keeps every decoder weight in registers / LDS; otherwise seven launches per step over the whole chip (a hipGraph
  * per 32 steps).  ttsx_t1_set_plan overrides the choice. */
 int ttsx_t1_decoder_run(ttsx_t1* m, const float* enc, const int32_t* lengths, int B, int T, int max_decoder_steps,

@@ -695,7 +695,7 @@ extern "C" int ttsx_t1_decoder_run(ttsx_t1* m, const float* enc, const int32_t* 
   // processed annotations, once per utterance (LocationSensitiveAttention caches them, :82-83)
   int rc = convmfma::layer_run(m->annot, enc, ENC_D, m->ws_annot, ATT_D, 0, nullptr, 0, nullptr, B, T, st);
   if (rc) return rc;
-  // Batch 1-2 with a text of up to 128 symbols: one persistent launch of a 33-workgroup team per utterance with
+  // Batch 1-2 with a text of up to 128 symbols: one persistent launch of a 36-workgroup team per utterance with
   // all decoder weights on chip (t1_team.hip).  Otherwise seven launches per step over the whole chip
   // (t1_steps, in t2_decoder.hip); a memory queue longer than 512 floats leaves only the
   // one-workgroup-per-utterance kernel below.  ttsx_t1_set_plan overrides the choice where the shapes allow.

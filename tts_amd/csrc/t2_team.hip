@@ -34,7 +34,7 @@
 // to the next step's attention LSTM, both of which need it later than the decoder LSTM did.
 // A free run ends through the data: the workgroup that owns the stop row marks the words it publishes, and every
 // workgroup that sees a marked word marks what it publishes and leaves.  Every wait is bounded: a team that is not
-// resident together (other kernels hold CUs) raises an abort word after ~2 s and the host reports it.
+// resident together (other kernels hold CUs) raises an abort word after 50 ms of wall-clock time and the host reports it.
 #include <algorithm>
 #include <mutex>
 #include <vector>
