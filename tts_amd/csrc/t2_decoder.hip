@@ -1911,7 +1911,7 @@ struct ttsx_t2_decoder {
   struct ChunkGraph {
     hipGraphExec_t exec;
     int B, T, r, gen, chunk, split, fused;
-  } graphs[2];
+  } graphs[3];  // chunks of CHUNK, of the short (polling) size, of CHUNK_LONG steps
   hipStream_t cap_stream;  // capture-only stream: the caller's stream may be the legacy default stream
   int* host_words_dev;     // device-side address of host_flag (mapped pinned memory)
   int poll_chunk, poll_ahead;  // free run at batch 1-2: steps per graph and steps kept in flight (0: defaults)
@@ -1939,6 +1939,10 @@ namespace {
 // the smaller overshoot gives back; larger batches use the long chunk.  (Both even: the h ping-pong parity of a
 // chunk's steps is fixed at capture.)
 constexpr int CHUNK = 32, CHUNK_SHORT = 8;
+// Runs with a fixed number of steps poll nothing, so their graphs can be long: the first step of a graph has no
+// projection launch of a step before it to carry its prenet layer 2 and its early attention-LSTM columns (two
+// launches of its own, ~13 us at padded batch 64) - once per 160 steps instead of once per 32.
+constexpr int CHUNK_LONG = 160;
 int gemm_shape(int Bpad, int nrb);
 int query_groups(int B, int Bpad);
 hipError_t set_fused_lds();
@@ -2560,7 +2564,7 @@ int push_ctx(ttsx_t2_decoder* d, hipStream_t st) {
 // (B, T, r, workspace, launch plan) and chunk size.
 int launch_chunk(ttsx_t2_decoder* d, int n, int chunk, hipStream_t st) {
   if (n == chunk) {
-    ttsx_t2_decoder::ChunkGraph& g = d->graphs[chunk == CHUNK ? 0 : 1];   // (the cache key includes the chunk size)
+    ttsx_t2_decoder::ChunkGraph& g = d->graphs[chunk == CHUNK ? 0 : chunk == CHUNK_LONG ? 2 : 1];   // (the cache key includes the chunk size)
     const int split = (int)d->split + 2 * (int)d->share_q + 4 * (d->plan_fuse_p2 + 1) + 16 * (int)d->fuse_gave_up + 32 * (int)d->staged;
     const bool cached = g.exec && g.B == d->B && g.T == d->T && g.r == d->rc_host->r && g.gen == d->ws_gen &&
                         g.chunk == n && g.split == split && g.fused == (int)d->fused;
@@ -3038,8 +3042,9 @@ extern "C" int ttsx_t2_decoder_run(ttsx_t2_decoder* d, const float* enc, const i
   int launched = 0;
   if (fixed_steps) {
     while (launched < max_steps) {
-      const int n = std::min(CHUNK, max_steps - launched);
-      if ((rc = launch_chunk(d, n, CHUNK, st))) return rc;
+      const int chunk = max_steps - launched >= CHUNK_LONG ? CHUNK_LONG : CHUNK;
+      const int n = std::min(chunk, max_steps - launched);
+      if ((rc = launch_chunk(d, n, chunk, st))) return rc;
       launched += n;
     }
   } else {
