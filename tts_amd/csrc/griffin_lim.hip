@@ -486,14 +486,24 @@ __device__ __forceinline__ void pfft1024_pass3(f2 (&v)[16], f2* s, const f2* s_t
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[4 * i + r] = s[bl + 68 * i + 272 * r];
   }
+  // Twiddles W_1024^(m j), j = lane + 64 i, m = 1, 2, 3: W^(m lane) from the table (three reads per lane instead of
+  // twelve - the LDS pipe is the busier one in this kernel) times W_16^(i m), a constant of the unrolled code.
+  const int jl = lane + z;
+  const f2 t1 = s_tw[jl], t2 = s_tw[2 * jl], t3 = s_tw[3 * jl];
+  constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, C2 = 0.70710678118654752f;
+  const f2 b1 = {C1, S1}, b2 = {C2, C2}, b3 = {S1, C1}, b6 = {-C2, C2}, b9 = {-C1, -S1};  // W_16^m at positive angle
+  v[1] = pk_cmul<INV>(v[1], t1), v[2] = pk_cmul<INV>(v[2], t2), v[3] = pk_cmul<INV>(v[3], t3);
+  v[5] = pk_cmul<INV>(pk_cmulc<!INV>(v[5], b1), t1);
+  v[6] = pk_cmul<INV>(pk_cmulc<!INV>(v[6], b2), t2);
+  v[7] = pk_cmul<INV>(pk_cmulc<!INV>(v[7], b3), t3);
+  v[9] = pk_cmul<INV>(pk_cmulc<!INV>(v[9], b2), t1);
+  v[10] = pk_cmul<INV>(pk_mulj<!INV>(v[10]), t2);
+  v[11] = pk_cmul<INV>(pk_cmulc<!INV>(v[11], b6), t3);
+  v[13] = pk_cmul<INV>(pk_cmulc<!INV>(v[13], b3), t1);
+  v[14] = pk_cmul<INV>(pk_cmulc<!INV>(v[14], b6), t2);
+  v[15] = pk_cmul<INV>(pk_cmulc<!INV>(v[15], b9), t3);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int j = lane + 64 * i + z;
-    v[4 * i + 1] = pk_cmul<INV>(v[4 * i + 1], s_tw[j]);
-    v[4 * i + 2] = pk_cmul<INV>(v[4 * i + 2], s_tw[2 * j]);
-    v[4 * i + 3] = pk_cmul<INV>(v[4 * i + 3], s_tw[3 * j]);
-    pdft4<INV>(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
-  }
+  for (int i = 0; i < 4; ++i) pdft4<INV>(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
 }
 
 // One Griffin-Lim iteration of one frame (utterance b, frame i) by one wave; the windowed synthesis frame (samples
