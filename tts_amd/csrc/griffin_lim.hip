@@ -816,6 +816,11 @@ __global__ __launch_bounds__(64 * FR_PER_WG, 3) void gl_fused_kernel(FusedP P) {
                         FR_PER_WG * j_first + FR_PER_WG - 1 < Fb;
   float* stash = defer_me ? P.stash + ((size_t)b * gridDim.x + blockIdx.x) * 6 * q.hop : nullptr;
   const int j_start = max(j_first - ((xmode || defer_me) ? 0 : P.n_halo), 0);  // (nothing before the first frame)
+  // (several rounds per workgroup) the next round's samples are requested while this round is combined
+  [[maybe_unused]] FrameIn fin_next;
+  if constexpr (!ONE && KIND == K_GL_ITER) {
+    if (j_start < j_end && FR_PER_WG * j_start + wave < Fb) frame_prefetch<PRUNE>(p, b, FR_PER_WG * j_start + wave, lane, fin_next);
+  }
   for (int j = j_start; j < j_end; ++j) {
     __syncthreads();      // tables / carry ready; the previous round's combine has read the frames
     const int i = FR_PER_WG * j + wave;
@@ -829,12 +834,13 @@ __global__ __launch_bounds__(64 * FR_PER_WG, 3) void gl_fused_kernel(FusedP P) {
         if constexpr (ONE) {
           frame_iter<PRUNE>(p, b, i, s_data[wave], s_tw, s_tw2, lane, fin_early, mark);
         } else {
-          FrameIn fin;
-          frame_prefetch<PRUNE>(p, b, i, lane, fin);
-          frame_iter<PRUNE>(p, b, i, s_data[wave], s_tw, s_tw2, lane, fin, mark);
+          frame_iter<PRUNE>(p, b, i, s_data[wave], s_tw, s_tw2, lane, fin_next, mark);
         }
       }
       else frame_body<KIND, true>(p, b, i, s_data[wave], s_tw, s_tw2, lane);
+    }
+    if constexpr (!ONE && KIND == K_GL_ITER) {
+      if (j + 1 < j_end && i + FR_PER_WG < Fb) frame_prefetch<PRUNE>(p, b, i + FR_PER_WG, lane, fin_next);
     }
     __syncthreads();
     GL_MARK_NV(6);
