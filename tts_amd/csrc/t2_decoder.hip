@@ -556,6 +556,7 @@ struct GemmOp {
         if (threadIdx.x == 0) p.ctx->sync_failed = 1;
         return;  // (no barrier has been passed: the waves of the workgroup leave one by one)
       }
+      asm volatile("" ::: "memory");  // (the compiler keeps the loads below behind the looks at the tags)
       const float* xb = seg_ptr(p.seg[0], p.parity);
 #pragma unroll
       for (int i = 0; i < D; ++i)
@@ -908,6 +909,7 @@ struct Prenet2AfterProjOp {
       if (lane == 0) cx->sync_failed = 1;
       return;
     }
+    asm volatile("" ::: "memory");  // (the compiler keeps the loads below behind the flag loads)
     // (No acquire fence here and no release store on the producer's side: at agent scope they invalidate / write
     // back the L2 - measured +0.7 us on this launch.  x1 and the flags only move through agent-scope accesses that
     // bypass the caches which such fences would maintain; the producer waits for its x1 stores to be acknowledged
