@@ -503,6 +503,21 @@ int ttsx_request_tail(const float* wav, const int32_t* n_samples, int B, int pit
                       float threshold, int gap, int do_trim, int32_t* endpoints, int32_t* offsets, int16_t* pcm,
                       long capacity, long* total_host, float* peak_host, void* stream);
 
+/* ------------------------------------------------------------------ testing hook
+ *
+ * No counterpart in the reference.  Some launches here hold workgroups that wait - for a bounded time - for other
+ * workgroups of the same launch (the persistent teams of batch 1-2, the encoder scan, the fused launches of the
+ * batched decoder step).  A wait that expires makes the run start over on the plain launch chain (default plans) or
+ * fail with TTSX_ERR_STATE (a plan forced by its setter).  That only happens when other work holds the CUs, so a
+ * test cannot provoke it: this call makes the NEXT run of each named kind, on any handle of the process, report an
+ * expired wait once its launches have ended.  `kinds` is a sum of the values below.  For tests; a server has no use
+ * for it. */
+#define TTSX_WAIT_T2_STEP_FUSION 1 /* ttsx_t2_decoder_run, batched launch chain (ttsx_t2_decoder_set_fusion) */
+#define TTSX_WAIT_T2_TEAM 2        /* ttsx_t2_decoder_run, batch 1-2 (ttsx_t2_decoder_set_team) */
+#define TTSX_WAIT_T1_TEAM 4        /* ttsx_t1_decoder_run, batch 1-2 (ttsx_t1_set_plan) */
+#define TTSX_WAIT_ENCODER_SCAN 8   /* ttsx_encoder_lstm_run, batch 1-2 (ttsx_encoder_lstm_set_plan) */
+int ttsx_debug_fail_next_wait(unsigned kinds);
+
 #ifdef __cplusplus
 }
 #endif

@@ -106,6 +106,7 @@ def test_entry_points_reject_bad_arguments_before_any_device_call():
         "ttsx_vocoder_istft": lambda: lib.ttsx_vocoder_istft(None, one, one, 1, 8, one, None),
         "ttsx_request_tail": lambda: lib.ttsx_request_tail(None, None, 1, 100, 1024, 256, -40.0, 0, 0, one, one, one,
                                                            c_long(100), None, None, None),
+        "ttsx_debug_fail_next_wait": lambda: lib.ttsx_debug_fail_next_wait(16),
     }
     skipped = {"ttsx_last_error_string", "ttsx_version"}
     destroys = {k for k in _lib.PROTOTYPES if k.endswith("_destroy")}

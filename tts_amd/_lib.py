@@ -140,6 +140,7 @@ PROTOTYPES = {
     "ttsx_vocoder_istft": (c_int, [c_void_p, _fp, _fp, c_int, c_int, _fp, c_void_p]),
     "ttsx_request_tail": (c_int, [_fp, _fp, c_int, c_int, c_int, c_int, c_float, c_int, c_int, _fp, _fp, _fp,
                                   c_long, POINTER(c_long), POINTER(c_float), c_void_p]),
+    "ttsx_debug_fail_next_wait": (c_int, [ctypes.c_uint]),
 }
 
 _lib = None

@@ -15,6 +15,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 void ttsx_set_error(const char* fmt, ...);
 std::mutex& ttsx_team_mutex();  // serialises the persistent team kernels of a process (errors.cpp)
+// true once after ttsx_debug_fail_next_wait named this kind: the run that asks reports an expired wait (errors.cpp)
+bool ttsx_take_wait_failure(unsigned kind);
 
 #define TTSX_HIP(expr)                                                                     \
   do {                                                                                     \

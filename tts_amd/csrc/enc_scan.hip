@@ -185,7 +185,7 @@ int enc_scan_run(const EncScanArgs& a, hipStream_t st) {
   p.out = a.out, p.len = a.len, p.h_state = a.h_state, p.c_state = a.c_state, p.abort_word = a.abort_word;
   p.T = a.T, p.B = a.B, p.Bc = a.Bc, p.Bx = Bx, p.Ct = a.Ct;
   TTSX_HIP(hipMemsetAsync(a.steps, 0, sizeof(unsigned) * 2 * ncg * NRB, st));
-  TTSX_HIP(hipMemsetAsync(a.abort_word, 0, sizeof(int), st));
+  TTSX_HIP(hipMemsetAsync(a.abort_word, ttsx_take_wait_failure(TTSX_WAIT_ENCODER_SCAN) ? 1 : 0, sizeof(int), st));
   enc_scan_init_kernel<<<ceil_div(2 * H * Bx, 256), 256, 0, st>>>(p.hx[0], p.hx[1], a.h_state, a.B, Bx);
   TTSX_LAUNCH_CHECK();
   const int grid = 2 * NRB * ncg;

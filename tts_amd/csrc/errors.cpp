@@ -2,6 +2,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 
+#include <atomic>
 #include <mutex>
 
 #include "../../include/ttsx.h"
@@ -26,3 +27,15 @@ std::mutex& ttsx_team_mutex() {
   static std::mutex m;
   return m;
 }
+
+// Testing hook: kinds of bounded in-launch wait whose next run is to report an expired wait.
+static std::atomic<unsigned> g_fail_waits{0};
+extern "C" int ttsx_debug_fail_next_wait(unsigned kinds) {
+  if (kinds & ~15u) {
+    ttsx_set_error("ttsx_debug_fail_next_wait: kinds=%u holds bits outside the four TTSX_WAIT_ values", kinds);
+    return TTSX_ERR_ARG;
+  }
+  g_fail_waits.fetch_or(kinds);
+  return TTSX_OK;
+}
+bool ttsx_take_wait_failure(unsigned kind) { return (g_fail_waits.fetch_and(~kind) & kind) != 0; }

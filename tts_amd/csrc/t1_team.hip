@@ -898,7 +898,7 @@ int t1_team_run(t1_team* t, const float* enc, const float* annot, const int32_t*
   std::lock_guard<std::mutex> one_team(ttsx_team_mutex());  // until the synchronisation below
   // tags start at 1: all-zero words match no step
   TTSX_HIP(hipMemsetAsync(t->xch, 0, sizeof(u64) * (size_t)B * X_TEAM, st));
-  TTSX_HIP(hipMemsetAsync(t->abort_word, 0, sizeof(int), st));
+  TTSX_HIP(hipMemsetAsync(t->abort_word, ttsx_take_wait_failure(TTSX_WAIT_T1_TEAM) ? 1 : 0, sizeof(int), st));
   TTSX_HIP(hipMemsetAsync(n_steps, 0, sizeof(int32_t) * B, st));
   TeamP p{};
   p.img = t->img, p.w2t = t->w2t, p.b2 = t->b2, p.mem_init = t->mem_init, p.att_init = t->att_init;

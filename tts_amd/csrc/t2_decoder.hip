@@ -3037,6 +3037,7 @@ extern "C" int ttsx_t2_decoder_run(ttsx_t2_decoder* d, const float* enc, const i
   h->r = r, h->free_running = fixed_steps ? 0 : 1, h->threshold = stop_threshold;
   h->mel = mel, h->mel_rows = max_steps * r, h->align = align, h->align_rows = max_steps;
   h->stop = stop, h->stop_rows = max_steps, h->n_steps = n_steps;
+  h->sync_failed = ttsx_take_wait_failure(TTSX_WAIT_T2_STEP_FUSION) ? 1 : 0;
   h->host_words = fixed_steps ? nullptr : d->host_words_dev;
   d->host_flag[0] = 0, d->host_flag[1] = 0;
   rc = push_ctx(d, st);

@@ -1345,7 +1345,7 @@ int t2_team_run(t2_team* t, const float* enc, const float* P, const int32_t* len
   std::lock_guard<std::mutex> one_team(ttsx_team_mutex());  // until the synchronisation below
   // tags start at 1: all-zero words match no step
   TTSX_HIP(hipMemsetAsync(t->xch, 0, sizeof(u64) * 2 * X_PAR, st));
-  TTSX_HIP(hipMemsetAsync(t->abort_word, 0, sizeof(int), st));
+  TTSX_HIP(hipMemsetAsync(t->abort_word, ttsx_take_wait_failure(TTSX_WAIT_T2_TEAM) ? 1 : 0, sizeof(int), st));
   T2P p{};
   p.img_att = t->img_att, p.lds_att = t->lds_att, p.img_dec = t->img_dec, p.lds_dec = t->lds_dec;
   p.img_proj = t->img_proj, p.img_en = t->img_en, p.conv_t = t->conv_t, p.loc_dense = t->loc_dense;
